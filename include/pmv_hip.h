@@ -1,0 +1,113 @@
+/* pmv_hip.h — C ABI of the MI355X (gfx950) visual-odometry hot path.
+ *
+ * Drop-in boundary: each entry point replaces the third-party call that one of the
+ * reference's plugin implementations makes behind its Base* interface.  Citations are into the
+ * reference tree (JeanElsner/practical-multi-view):
+ *
+ *   pmv_frame_upload / pmv_frames_upload   Frame::Frame + cv::buildOpticalFlowPyramid   (Frame.cpp:31-42,
+ *                                          implicit inside OpenCVLucasKanadeFM.cpp:15)
+ *   pmv_detect_gftt                        cv::goodFeaturesToTrack per grid cell         (OpenCVGoodFeatureExtractor.cpp:7,
+ *                                          called from OdometryPipeline.cpp:357 / :450)  -> BaseFeatureExtractor.h:21
+ *   pmv_detect_shitomasi                   ShiTomasiFeatureExtractor::extractFeatures    (ShiTomasiFeatureExtractor.cpp:5-75,
+ *                                          Frame.cpp:58-86,119-138)                      -> BaseFeatureExtractor.h:21
+ *   pmv_lk_track                           cv::calcOpticalFlowPyrLK                      (OpenCVLucasKanadeFM.cpp:15) -> BaseFeatureMatcher.h:22
+ *   pmv_pnp_ransac                         cv::solvePnPRansac                            (OpenCVEPnPSolver.cpp:35-36) -> BasePnPSolver.h:19
+ *   pmv_ba_residuals / pmv_ba_solve        ProjectionResidual + ceres::Solve             (ProjectionResidual.h:38-58,
+ *                                          CeresBundleAdjustment.cpp:50-61)              -> BaseOptimizer.h:15
+ *
+ * Conventions: plain pointers and sizes only; every in/out buffer is caller-allocated HOST memory
+ * unless a parameter is documented as a device frame slot; the opaque context owns all device
+ * memory and two HIP streams (front-end: detect/LK, back-end: PnP/BA — the reference's two threads,
+ * OdometryPipeline.cpp:261-262).  All functions return 0 on success or a negative pmv_status;
+ * pmv_last_error() gives the text.  Nothing throws across this boundary.  There is NO CPU fallback:
+ * if no gfx950 device / code object is available pmv_ctx_create fails.
+ */
+#ifndef PMV_HIP_H
+#define PMV_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pmv_ctx pmv_ctx;
+
+enum pmv_status {
+    PMV_OK = 0,
+    PMV_ERR_NO_DEVICE = -1,   /* no HIP device / wrong arch */
+    PMV_ERR_INVALID = -2,     /* bad argument (null, size, slot out of range) */
+    PMV_ERR_CAPACITY = -3,    /* exceeds the capacity given at pmv_ctx_create */
+    PMV_ERR_HIP = -4,         /* HIP runtime error, see pmv_last_error */
+    PMV_ERR_DEGENERATE = -5,  /* e.g. fewer than 5 PnP points (cv::Exception in the reference) */
+    PMV_ERR_OVERFLOW = -6     /* internal candidate list overflow */
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* max_w/max_h: largest frame; n_slots: device frame slots (each holds a padded 8-bit pyramid);
+ * max_tracks: largest N for lk_track / M for pnp; max_ba_cams / max_ba_points / max_ba_obs: BA caps. */
+int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots, int max_tracks,
+                   int max_ba_cams, int max_ba_points, int max_ba_obs);
+void pmv_ctx_destroy(pmv_ctx* ctx);
+const char* pmv_last_error(pmv_ctx* ctx); /* ctx may be NULL for create-time errors */
+int pmv_sync(pmv_ctx* ctx);               /* waits for both streams */
+
+/* ---- frames / pyramids ----------------------------------------------------------------------- */
+/* Copy one 8-bit gray frame (host) into `slot` and build its LK pyramid (levels as cv::buildOpticalFlowPyramid
+ * with winSize 32, maxLevel 4). */
+int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, int stride);
+/* Batch form: n frames, tightly packed (n*w*h bytes), into slots first_slot..first_slot+n-1. The gray data
+ * is staged to HBM first (pmv_frames_stage), the pyramids are built by pmv_frames_build so that a benchmark can
+ * time the build with inputs already resident in HBM. */
+int pmv_frames_stage(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, int w, int h);
+int pmv_frames_build(pmv_ctx* ctx, int first_slot, int n);
+/* Debug/parity: copy pyramid level `level` of `slot` (unpadded, tightly packed) back to host. Returns level dims. */
+int pmv_frame_get_level(pmv_ctx* ctx, int slot, int level, uint8_t* out, int* w, int* h);
+int pmv_frame_num_levels(pmv_ctx* ctx, int slot); /* maxLevel actually built (>=0) or <0 */
+
+/* ---- feature extraction ------------------------------------------------------------------------ */
+/* cells: n_cells * 4 ints (x0, y0, w, h), each <= 255x255, sub-views of the frame in `slot`.
+ * out_xy: n_cells * max_per_cell * 2 ints, CELL-LOCAL (x, y) in descending-response order as OpenCV returns them;
+ * out_count: n_cells ints. */
+int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
+                    double min_dist, int* out_xy, int* out_count);
+/* Same geometry; out_score: n_cells * max_per_cell doubles (the reference fills Feature::score). */
+int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
+                         int* out_xy, double* out_score, int* out_count);
+/* Debug/parity: response map of one cell (GFTT: float32 min-eigenvalue map before thresholding). */
+int pmv_debug_gftt_response(pmv_ctx* ctx, int slot, const int* cell, float* out);
+int pmv_debug_shitomasi_response(pmv_ctx* ctx, int slot, const int* cell, double* out);
+
+/* ---- feature matching ----------------------------------------------------------------------------- */
+/* Pyramidal LK from frame slot `prev_slot` to `next_slot`. prev_xy: n*2 floats. out_xy n*2 floats,
+ * out_status n bytes, out_err n floats (exactly the three outputs of cv::calcOpticalFlowPyrLK). */
+int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy,
+                 uint8_t* out_status, float* out_err);
+
+/* ---- PnP ------------------------------------------------------------------------------------------------ */
+/* obj_xyz m*3 float32, img_xy m*2 float32, K 9 doubles row-major, rvec/tvec 3 doubles in/out
+ * (useExtrinsicGuess=true semantics of the reference call), out_inliers: capacity m ints. */
+int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec,
+                   double* tvec, int iterations, float reproj_err, double confidence, int* out_inliers,
+                   int* out_n_inliers);
+
+/* ---- bundle adjustment ------------------------------------------------------------------------------------- */
+typedef struct pmv_ba_summary {
+    double initial_cost, final_cost;
+    int iterations;       /* LM iterations executed (successful + unsuccessful) */
+    int successful_steps;
+    int termination;      /* 0 = max iterations, 1 = function tol, 2 = gradient tol, 3 = parameter tol, 4 = failure */
+} pmv_ba_summary;
+
+/* Per-observation residuals (n_obs*2) and Jacobians (n_obs*2*9: d r / d cam[6], d r / d point[3]) of
+ * ProjectionResidual (ProjectionResidual.h:38-58). cams nc*6 = [angle-axis(R^T), -t], pts np*3 doubles. */
+int pmv_ba_residuals(pmv_ctx* ctx, const double* cams, int nc, const double* pts, int np, const double* obs_xy,
+                     const int* cam_idx, const int* pt_idx, int n_obs, const double* K, double* out_r,
+                     double* out_J);
+/* Levenberg–Marquardt with Huber(huber_delta) loss and Schur elimination of the points; cams/pts updated in place. */
+int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
+                 const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations,
+                 pmv_ba_summary* summary);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

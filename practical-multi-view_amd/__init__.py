@@ -1,0 +1,231 @@
+"""practical-multi-view_amd — MI355X (gfx950) visual-odometry hot path behind the reference's plugin roles.
+
+Python here is plumbing only: a ctypes binding of the C ABI in include/pmv_hip.h (the product is the HIP library
+`libpmv_hip.so` built by build.py) plus thin mirrors of the reference's plugin roles used by tests and bench.py.
+There is NO CPU fallback: creating a Context without a gfx950 device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+
+class PmvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pmv error {code}: {msg}")
+        self.code = code
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int),
+                ("successful_steps", C.c_int), ("termination", C.c_int)]
+
+
+# every symbol include/pmv_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
+    "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frame_get_level", "pmv_frame_num_levels",
+    "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
+    "pmv_lk_track", "pmv_pnp_ransac", "pmv_ba_residuals", "pmv_ba_solve",
+]
+
+_lib = None
+_synth = None
+
+
+def lib_path():
+    return os.path.join(HERE, "libpmv_hip.so")
+
+
+def load_library():
+    """dlopen the product library (must have been built: __graft_entry__.build() or build.build_hip())."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise PmvError(-1, f"{p} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+        _lib.pmv_last_error.restype = C.c_char_p
+        _lib.pmv_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def load_synth():
+    global _synth
+    if _synth is None:
+        _synth = C.CDLL(_build.build_synth())
+    return _synth
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def synth_sequence(seed, first, n, w, h, fx, fy, cx, cy, nthreads=8):
+    """n deterministic synthetic KITTI-like frames (n, h, w) uint8 + their KITTI pose rows (n, 12)."""
+    s = load_synth()
+    out = np.empty((n, h, w), np.uint8)
+    s.pmv_synth_sequence(C.c_uint64(seed), first, n, w, h, C.c_double(fx), C.c_double(fy), C.c_double(cx),
+                         C.c_double(cy), _p(out, _u8p), nthreads)
+    poses = np.empty((n, 12), np.float64)
+    for i in range(n):
+        s.pmv_synth_pose(C.c_uint64(seed), first + i, _p(poses[i], _f64p))
+    return out, poses
+
+
+def grid_cells(w, h, gw=255, gh=255):
+    """OdometryPipeline::getGridROI (reference OdometryPipeline.cpp:674-693): row-major cells (x0, y0, cw, ch)."""
+    cells = []
+    for r in range(0, h, gh):
+        for c in range(0, w, gw):
+            cells.append((c, r, min(gw, w - c), min(gh, h - r)))
+    return np.asarray(cells, np.int32)
+
+
+class Context:
+    """Opaque device context (owns HBM frame slots, workspaces and the front-end/back-end HIP streams)."""
+
+    def __init__(self, max_w, max_h, n_slots=2, max_tracks=4096, max_ba_cams=32, max_ba_points=8192,
+                 max_ba_obs=65536, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.pmv_ctx_create(C.byref(self.h), device, max_w, max_h, n_slots, max_tracks, max_ba_cams,
+                                     max_ba_points, max_ba_obs)
+        if rc != 0:
+            raise PmvError(rc, self.lib.pmv_last_error(None).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.pmv_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PmvError(rc, self.lib.pmv_last_error(self.h).decode())
+
+    def sync(self):
+        self._ck(self.lib.pmv_sync(self.h))
+
+    # ---- frames ----
+    def frame_upload(self, slot, gray):
+        g = np.ascontiguousarray(gray, np.uint8)
+        self._ck(self.lib.pmv_frame_upload(self.h, slot, _p(g, _u8p), g.shape[1], g.shape[0], g.shape[1]))
+
+    def frames_stage(self, first_slot, frames):
+        f = np.ascontiguousarray(frames, np.uint8)
+        self._ck(self.lib.pmv_frames_stage(self.h, first_slot, f.shape[0], _p(f, _u8p), f.shape[2], f.shape[1]))
+
+    def frames_build(self, first_slot, n):
+        self._ck(self.lib.pmv_frames_build(self.h, first_slot, n))
+
+    def num_levels(self, slot):
+        return self.lib.pmv_frame_num_levels(self.h, slot)
+
+    def get_level(self, slot, level, max_w, max_h):
+        out = np.zeros(max_w * max_h, np.uint8)
+        w, h = C.c_int(), C.c_int()
+        self._ck(self.lib.pmv_frame_get_level(self.h, slot, level, _p(out, _u8p), C.byref(w), C.byref(h)))
+        return out[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    # ---- BaseFeatureExtractor role ----
+    def detect_gftt(self, slot, cells, max_per_cell, quality=0.01, min_dist=5.0):
+        cells = np.ascontiguousarray(cells, np.int32).reshape(-1, 4)
+        n = cells.shape[0]
+        xy = np.zeros((n, max_per_cell, 2), np.int32)
+        cnt = np.zeros(n, np.int32)
+        self._ck(self.lib.pmv_detect_gftt(self.h, slot, _p(cells, _i32p), n, max_per_cell, C.c_double(quality),
+                                          C.c_double(min_dist), _p(xy, _i32p), _p(cnt, _i32p)))
+        return [xy[i, : cnt[i]].copy() for i in range(n)]
+
+    def detect_shitomasi(self, slot, cells, max_per_cell, quality=0.4):
+        cells = np.ascontiguousarray(cells, np.int32).reshape(-1, 4)
+        n = cells.shape[0]
+        xy = np.zeros((n, max_per_cell, 2), np.int32)
+        sc = np.zeros((n, max_per_cell), np.float64)
+        cnt = np.zeros(n, np.int32)
+        self._ck(self.lib.pmv_detect_shitomasi(self.h, slot, _p(cells, _i32p), n, max_per_cell, C.c_double(quality),
+                                               _p(xy, _i32p), _p(sc, _f64p), _p(cnt, _i32p)))
+        return [(xy[i, : cnt[i]].copy(), sc[i, : cnt[i]].copy()) for i in range(n)]
+
+    def gftt_response(self, slot, cell):
+        cell = np.ascontiguousarray(cell, np.int32)
+        out = np.zeros((cell[3], cell[2]), np.float32)
+        self._ck(self.lib.pmv_debug_gftt_response(self.h, slot, _p(cell, _i32p), _p(out, _f32p)))
+        return out
+
+    def shitomasi_response(self, slot, cell):
+        cell = np.ascontiguousarray(cell, np.int32)
+        out = np.zeros((cell[3], cell[2]), np.float64)
+        self._ck(self.lib.pmv_debug_shitomasi_response(self.h, slot, _p(cell, _i32p), _p(out, _f64p)))
+        return out
+
+    # ---- BaseFeatureMatcher role ----
+    def lk_track(self, prev_slot, next_slot, prev_xy):
+        p = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+        n = p.shape[0]
+        out = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        self._ck(self.lib.pmv_lk_track(self.h, prev_slot, next_slot, _p(p, _f32p), n, _p(out, _f32p), _p(st, _u8p),
+                                       _p(err, _f32p)))
+        return out, st, err
+
+    # ---- BasePnPSolver role ----
+    def pnp_ransac(self, obj_xyz, img_xy, K, rvec, tvec, iterations=100, reproj_err=8.0, confidence=0.99):
+        o = np.ascontiguousarray(obj_xyz, np.float32).reshape(-1, 3)
+        i2 = np.ascontiguousarray(img_xy, np.float32).reshape(-1, 2)
+        m = o.shape[0]
+        Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+        rv = np.array(rvec, np.float64).reshape(3).copy()
+        tv = np.array(tvec, np.float64).reshape(3).copy()
+        inl = np.zeros(max(m, 1), np.int32)
+        nin = C.c_int()
+        self._ck(self.lib.pmv_pnp_ransac(self.h, _p(o, _f32p), _p(i2, _f32p), m, _p(Kd, _f64p), _p(rv, _f64p),
+                                         _p(tv, _f64p), iterations, C.c_float(reproj_err), C.c_double(confidence),
+                                         _p(inl, _i32p), C.byref(nin)))
+        return rv, tv, inl[: nin.value].copy()
+
+    # ---- BaseOptimizer role ----
+    def ba_residuals(self, cams, pts, obs_xy, cam_idx, pt_idx, K):
+        cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 6)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+        ci = np.ascontiguousarray(cam_idx, np.int32)
+        pi = np.ascontiguousarray(pt_idx, np.int32)
+        Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+        n = obs.shape[0]
+        r = np.zeros((n, 2), np.float64)
+        J = np.zeros((n, 2, 9), np.float64)
+        self._ck(self.lib.pmv_ba_residuals(self.h, _p(cams, _f64p), cams.shape[0], _p(pts, _f64p), pts.shape[0],
+                                           _p(obs, _f64p), _p(ci, _i32p), _p(pi, _i32p), n, _p(Kd, _f64p),
+                                           _p(r, _f64p), _p(J, _f64p)))
+        return r, J
+
+    def ba_solve(self, cams, pts, obs_xy, cam_idx, pt_idx, K, huber=1.0, max_iterations=5):
+        cams = np.array(cams, np.float64).reshape(-1, 6).copy()
+        pts = np.array(pts, np.float64).reshape(-1, 3).copy()
+        obs = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+        ci = np.ascontiguousarray(cam_idx, np.int32)
+        pi = np.ascontiguousarray(pt_idx, np.int32)
+        Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+        s = BaSummary()
+        self._ck(self.lib.pmv_ba_solve(self.h, _p(cams, _f64p), cams.shape[0], _p(pts, _f64p), pts.shape[0],
+                                       _p(obs, _f64p), _p(ci, _i32p), _p(pi, _i32p), obs.shape[0], _p(Kd, _f64p),
+                                       C.c_double(huber), max_iterations, C.byref(s)))
+        return cams, pts, s

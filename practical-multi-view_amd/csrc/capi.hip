@@ -1,0 +1,312 @@
+// C-ABI implementation (include/pmv_hip.h): context, frame slots, launches, D2H staging.
+#include "pmv_ctx.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+using namespace pmv;
+
+static thread_local char g_create_err[512] = "";
+
+void pmv::set_err(pmv_ctx* c, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c ? c->err : g_create_err, 512, fmt, ap);
+    va_end(ap);
+}
+
+PyrLayout pmv::make_layout(int w, int h) {
+    PyrLayout L;
+    memset(&L, 0, sizeof(L));
+    // cv::buildOpticalFlowPyramid(img, pyr, Size(32,32), maxLevel=4): stop when the next level would be <= winSize
+    int lw = w, lh = h, n = 0;
+    uint32_t off = 0;
+    for (int level = 0; level <= 4; level++) {
+        L.w[level] = lw; L.h[level] = lh;
+        L.stride[level] = (lw + 2 * PAD + 63) & ~63;
+        L.off[level] = off;
+        off += (uint32_t)L.stride[level] * (uint32_t)(lh + 2 * PAD);
+        n = level + 1;
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+        if (lw <= LK_WIN || lh <= LK_WIN) break;
+    }
+    L.n_levels = n;
+    L.gray_off = off;
+    off += (uint32_t)((w * h + 255) & ~255);
+    L.slot_bytes = (off + 4095) & ~4095u;
+    return L;
+}
+
+extern "C" {
+
+const char* pmv_last_error(pmv_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots, int max_tracks, int max_ba_cams,
+                   int max_ba_points, int max_ba_obs) {
+    if (!out || max_w < 40 || max_h < 40 || n_slots < 1 || max_tracks < 1) {
+        set_err(nullptr, "pmv_ctx_create: invalid argument");
+        return PMV_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+        set_err(nullptr, "pmv_ctx_create: no HIP device %d (count %d) — this library has no CPU fallback", device, ndev);
+        return PMV_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_err(nullptr, "hipGetDeviceProperties failed"); return PMV_ERR_HIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(nullptr, "pmv_ctx_create: device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
+        return PMV_ERR_NO_DEVICE;
+    }
+    pmv_ctx* c = new pmv_ctx();
+    c->device = device;
+    c->max_w = max_w; c->max_h = max_h; c->n_slots = n_slots; c->max_tracks = max_tracks;
+    c->max_ba_cams = max_ba_cams; c->max_ba_points = max_ba_points; c->max_ba_obs = max_ba_obs;
+    c->cap = make_layout(max_w, max_h);
+    c->slot_layout.assign(n_slots, PyrLayout());
+    for (auto& l : c->slot_layout) l.n_levels = 0;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(nullptr, "%s: %s", #x, hipGetErrorString(e_)); pmv_ctx_destroy(c); return PMV_ERR_HIP; } } while (0)
+    CK(hipSetDevice(device));
+    CK(hipStreamCreateWithFlags(&c->s_front, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&c->s_back, hipStreamNonBlocking));
+    CK(hipMalloc(&c->d_slots, (size_t)c->cap.slot_bytes * n_slots));
+    const size_t nt = (size_t)max_tracks;
+    CK(hipMalloc(&c->d_prev_xy, nt * 8)); CK(hipMalloc(&c->d_out_xy, nt * 8));
+    CK(hipMalloc(&c->d_status, nt)); CK(hipMalloc(&c->d_err, nt * 4));
+    CK(hipHostMalloc(&c->h_prev_xy, nt * 8)); CK(hipHostMalloc(&c->h_out_xy, nt * 8));
+    CK(hipHostMalloc(&c->h_status, nt)); CK(hipHostMalloc(&c->h_err, nt * 4));
+    CK(hipMalloc(&c->d_cells, MAX_CELLS * 16));
+    CK(hipMalloc(&c->d_eig, (size_t)MAX_CELLS * CELL_PIX * sizeof(double)));   // shared by GFTT (f32) and ShiTomasi (f64)
+    CK(hipMalloc(&c->d_cellmax, MAX_CELLS * 8));
+    CK(hipMalloc(&c->d_det_xy, (size_t)MAX_CELLS * MAX_PER_CELL * 8));
+    CK(hipMalloc(&c->d_det_score, (size_t)MAX_CELLS * MAX_PER_CELL * 8));
+    CK(hipMalloc(&c->d_det_count, MAX_CELLS * 4));
+    CK(hipMalloc(&c->d_flags, 16));
+    CK(hipMemset(c->d_flags, 0, 16));
+    CK(hipHostMalloc(&c->h_det_xy, (size_t)MAX_CELLS * MAX_PER_CELL * 8));
+    CK(hipHostMalloc(&c->h_det_score, (size_t)MAX_CELLS * MAX_PER_CELL * 8));
+    CK(hipHostMalloc(&c->h_det_count, MAX_CELLS * 4 + 16));
+    int rc = backend_create(c);
+    if (rc != PMV_OK) { snprintf(g_create_err, sizeof(g_create_err), "%s", c->err); pmv_ctx_destroy(c); return rc; }
+#undef CK
+    *out = c;
+    return PMV_OK;
+}
+
+void pmv_ctx_destroy(pmv_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->s_front) hipStreamSynchronize(c->s_front);
+    if (c->s_back) hipStreamSynchronize(c->s_back);
+    backend_destroy(c);
+    hipFree(c->d_slots); hipFree(c->d_prev_xy); hipFree(c->d_out_xy); hipFree(c->d_status); hipFree(c->d_err);
+    hipHostFree(c->h_prev_xy); hipHostFree(c->h_out_xy); hipHostFree(c->h_status); hipHostFree(c->h_err);
+    hipFree(c->d_cells); hipFree(c->d_eig); hipFree(c->d_cellmax); hipFree(c->d_det_xy); hipFree(c->d_det_score);
+    hipFree(c->d_det_count); hipFree(c->d_flags);
+    hipHostFree(c->h_det_xy); hipHostFree(c->h_det_score); hipHostFree(c->h_det_count);
+    if (c->s_front) hipStreamDestroy(c->s_front);
+    if (c->s_back) hipStreamDestroy(c->s_back);
+    delete c;
+}
+
+#define CKC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(ctx, "%s: %s", #x, hipGetErrorString(e_)); return PMV_ERR_HIP; } } while (0)
+#define REQ(cond, code, ...) do { if (!(cond)) { set_err(ctx, __VA_ARGS__); return code; } } while (0)
+
+int pmv_sync(pmv_ctx* ctx) {
+    REQ(ctx, PMV_ERR_INVALID, "null ctx");
+    CKC(hipStreamSynchronize(ctx->s_front));
+    CKC(hipStreamSynchronize(ctx->s_back));
+    return PMV_OK;
+}
+
+static int build_levels(pmv_ctx* ctx, int first_slot, int n, const PyrLayout& L) {
+    CKC(launch_pad_level0(ctx->s_front, ctx->d_slots, L, first_slot, n));
+    for (int l = 1; l < L.n_levels; l++) CKC(launch_pyrdown(ctx->s_front, ctx->d_slots, L, l, first_slot, n));
+    return PMV_OK;
+}
+
+// NOTE: slots are addressed with the CAPACITY slot size (ctx->cap.slot_bytes); a frame smaller than max_w x max_h
+// uses its own level geometry inside the slot but the same slot pitch.
+static PyrLayout layout_for(pmv_ctx* ctx, int w, int h) {
+    PyrLayout L = make_layout(w, h);
+    L.slot_bytes = ctx->cap.slot_bytes;
+    return L;
+}
+
+int pmv_frames_stage(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, int w, int h) {
+    REQ(ctx && gray, PMV_ERR_INVALID, "pmv_frames_stage: null argument");
+    REQ(first_slot >= 0 && n >= 1 && first_slot + n <= ctx->n_slots, PMV_ERR_CAPACITY, "pmv_frames_stage: slots [%d,%d) out of range (n_slots %d)", first_slot, first_slot + n, ctx->n_slots);
+    REQ(w >= 40 && h >= 40 && w <= ctx->max_w && h <= ctx->max_h, PMV_ERR_CAPACITY, "pmv_frames_stage: frame %dx%d outside capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+    CKC(hipSetDevice(ctx->device));
+    PyrLayout L = layout_for(ctx, w, h);
+    for (int i = 0; i < n; i++)
+        CKC(hipMemcpyAsync(ctx->d_slots + (size_t)(first_slot + i) * L.slot_bytes + L.gray_off, gray + (size_t)i * w * h,
+                           (size_t)w * h, hipMemcpyHostToDevice, ctx->s_front));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    for (int i = 0; i < n; i++) { ctx->slot_layout[first_slot + i] = L; ctx->slot_layout[first_slot + i].n_levels = -L.n_levels; }
+    return PMV_OK;
+}
+
+int pmv_frames_build(pmv_ctx* ctx, int first_slot, int n) {
+    REQ(ctx, PMV_ERR_INVALID, "null ctx");
+    REQ(first_slot >= 0 && n >= 1 && first_slot + n <= ctx->n_slots, PMV_ERR_CAPACITY, "pmv_frames_build: slot range");
+    CKC(hipSetDevice(ctx->device));
+    // consecutive slots with identical geometry are built in one batched launch per level
+    int i = 0;
+    while (i < n) {
+        PyrLayout L = ctx->slot_layout[first_slot + i];
+        REQ(L.n_levels != 0, PMV_ERR_INVALID, "pmv_frames_build: slot %d was never staged", first_slot + i);
+        int j = i + 1;
+        while (j < n && ctx->slot_layout[first_slot + j].w[0] == L.w[0] && ctx->slot_layout[first_slot + j].h[0] == L.h[0]) j++;
+        if (L.n_levels < 0) L.n_levels = -L.n_levels;
+        int rc = build_levels(ctx, first_slot + i, j - i, L);
+        if (rc) return rc;
+        for (int k = i; k < j; k++) ctx->slot_layout[first_slot + k].n_levels = L.n_levels;
+        i = j;
+    }
+    return PMV_OK;
+}
+
+int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, int stride) {
+    REQ(ctx && gray, PMV_ERR_INVALID, "pmv_frame_upload: null argument");
+    REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "pmv_frame_upload: slot %d out of range", slot);
+    REQ(w >= 40 && h >= 40 && w <= ctx->max_w && h <= ctx->max_h && stride >= w, PMV_ERR_CAPACITY, "pmv_frame_upload: frame %dx%d outside capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+    CKC(hipSetDevice(ctx->device));
+    PyrLayout L = layout_for(ctx, w, h);
+    CKC(hipMemcpy2DAsync(ctx->d_slots + (size_t)slot * L.slot_bytes + L.gray_off, w, gray, stride, w, h, hipMemcpyHostToDevice, ctx->s_front));
+    int rc = build_levels(ctx, slot, 1, L);
+    if (rc) return rc;
+    CKC(hipStreamSynchronize(ctx->s_front));   // the host buffer may be reused by the caller
+    ctx->slot_layout[slot] = L;
+    return PMV_OK;
+}
+
+int pmv_frame_num_levels(pmv_ctx* ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= ctx->n_slots) return PMV_ERR_INVALID;
+    const int n = ctx->slot_layout[slot].n_levels;
+    return n > 0 ? n - 1 : PMV_ERR_INVALID;
+}
+
+int pmv_frame_get_level(pmv_ctx* ctx, int slot, int level, uint8_t* out, int* w, int* h) {
+    REQ(ctx && out, PMV_ERR_INVALID, "null argument");
+    REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "slot out of range");
+    const PyrLayout& L = ctx->slot_layout[slot];
+    REQ(L.n_levels > 0 && level >= 0 && level < L.n_levels, PMV_ERR_INVALID, "level %d not built for slot %d", level, slot);
+    CKC(hipSetDevice(ctx->device));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    const uint8_t* org = level_origin((const uint8_t*)ctx->d_slots + (size_t)slot * L.slot_bytes, L, level);
+    CKC(hipMemcpy2D(out, L.w[level], org, L.stride[level], L.w[level], L.h[level], hipMemcpyDeviceToHost));
+    if (w) *w = L.w[level];
+    if (h) *h = L.h[level];
+    return PMV_OK;
+}
+
+int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy,
+                 uint8_t* out_status, float* out_err) {
+    REQ(ctx && (n == 0 || (prev_xy && out_xy && out_status && out_err)), PMV_ERR_INVALID, "pmv_lk_track: null argument");
+    REQ(n >= 0 && n <= ctx->max_tracks, PMV_ERR_CAPACITY, "pmv_lk_track: n=%d exceeds max_tracks=%d", n, ctx->max_tracks);
+    REQ(prev_slot >= 0 && prev_slot < ctx->n_slots && next_slot >= 0 && next_slot < ctx->n_slots, PMV_ERR_CAPACITY, "pmv_lk_track: slot out of range");
+    const PyrLayout& L = ctx->slot_layout[prev_slot];
+    const PyrLayout& L2 = ctx->slot_layout[next_slot];
+    REQ(L.n_levels > 0 && L2.n_levels > 0, PMV_ERR_INVALID, "pmv_lk_track: slot has no pyramid");
+    REQ(L.w[0] == L2.w[0] && L.h[0] == L2.h[0], PMV_ERR_INVALID, "pmv_lk_track: frame sizes differ");
+    if (n == 0) return PMV_OK;
+    CKC(hipSetDevice(ctx->device));
+    memcpy(ctx->h_prev_xy, prev_xy, (size_t)n * 8);
+    CKC(hipMemcpyAsync(ctx->d_prev_xy, ctx->h_prev_xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->s_front));
+    LKParams P;
+    P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f;
+    CKC(launch_lk(ctx->s_front, ctx->d_slots + (size_t)prev_slot * L.slot_bytes, ctx->d_slots + (size_t)next_slot * L.slot_bytes,
+                  L, ctx->d_prev_xy, n, P, ctx->d_out_xy, ctx->d_status, ctx->d_err));
+    CKC(hipMemcpyAsync(ctx->h_out_xy, ctx->d_out_xy, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipMemcpyAsync(ctx->h_status, ctx->d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipMemcpyAsync(ctx->h_err, ctx->d_err, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    memcpy(out_xy, ctx->h_out_xy, (size_t)n * 8);
+    memcpy(out_status, ctx->h_status, (size_t)n);
+    memcpy(out_err, ctx->h_err, (size_t)n * 4);
+    return PMV_OK;
+}
+
+static int check_cells(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell) {
+    REQ(ctx && cells, PMV_ERR_INVALID, "detect: null argument");
+    REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "detect: slot out of range");
+    REQ(n_cells >= 1 && n_cells <= MAX_CELLS, PMV_ERR_CAPACITY, "detect: n_cells=%d (max %d)", n_cells, MAX_CELLS);
+    REQ(max_per_cell >= 1 && max_per_cell <= MAX_PER_CELL, PMV_ERR_CAPACITY, "detect: max_per_cell=%d (max %d)", max_per_cell, MAX_PER_CELL);
+    const PyrLayout& L = ctx->slot_layout[slot];
+    REQ(L.n_levels > 0, PMV_ERR_INVALID, "detect: slot %d has no frame", slot);
+    for (int i = 0; i < n_cells; i++) {
+        const int* c = cells + 4 * i;
+        REQ(c[2] >= 3 && c[3] >= 3 && c[2] <= CELL_MAX && c[3] <= CELL_MAX && c[0] >= 0 && c[1] >= 0 && c[0] + c[2] <= L.w[0] && c[1] + c[3] <= L.h[0],
+            PMV_ERR_INVALID, "detect: cell %d (%d,%d,%d,%d) invalid for %dx%d frame", i, c[0], c[1], c[2], c[3], L.w[0], L.h[0]);
+    }
+    return PMV_OK;
+}
+
+int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
+                    double min_dist, int* out_xy, int* out_count) {
+    int rc = check_cells(ctx, slot, cells, n_cells, max_per_cell);
+    if (rc) return rc;
+    REQ(out_xy && out_count, PMV_ERR_INVALID, "pmv_detect_gftt: null output");
+    CKC(hipSetDevice(ctx->device));
+    const PyrLayout& L = ctx->slot_layout[slot];
+    CKC(hipMemcpyAsync(ctx->d_cells, cells, (size_t)n_cells * 16, hipMemcpyHostToDevice, ctx->s_front));
+    CKC(launch_gftt(ctx->s_front, ctx->d_slots + (size_t)slot * L.slot_bytes, L, ctx->d_cells, n_cells, max_per_cell, quality,
+                    min_dist, (float*)ctx->d_eig, (unsigned*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_count, ctx->d_flags));
+    const size_t nxy = (size_t)n_cells * max_per_cell * 8;
+    CKC(hipMemcpyAsync(ctx->h_det_xy, ctx->d_det_xy, nxy, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipMemcpyAsync(ctx->h_det_count, ctx->d_det_count, (size_t)n_cells * 4, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipMemcpyAsync(ctx->h_det_count + MAX_CELLS, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    REQ((ctx->h_det_count[MAX_CELLS] & 1) == 0, PMV_ERR_OVERFLOW, "pmv_detect_gftt: candidate list overflow");
+    memcpy(out_xy, ctx->h_det_xy, nxy);
+    memcpy(out_count, ctx->h_det_count, (size_t)n_cells * 4);
+    return PMV_OK;
+}
+
+int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
+                         int* out_xy, double* out_score, int* out_count) {
+    int rc = check_cells(ctx, slot, cells, n_cells, max_per_cell);
+    if (rc) return rc;
+    REQ(out_xy && out_score && out_count, PMV_ERR_INVALID, "pmv_detect_shitomasi: null output");
+    CKC(hipSetDevice(ctx->device));
+    const PyrLayout& L = ctx->slot_layout[slot];
+    CKC(hipMemcpyAsync(ctx->d_cells, cells, (size_t)n_cells * 16, hipMemcpyHostToDevice, ctx->s_front));
+    CKC(launch_shitomasi(ctx->s_front, ctx->d_slots + (size_t)slot * L.slot_bytes, L, ctx->d_cells, n_cells, max_per_cell, quality,
+                         ctx->d_eig, (unsigned long long*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_score, ctx->d_det_count, ctx->d_flags));
+    const size_t nxy = (size_t)n_cells * max_per_cell * 8;
+    CKC(hipMemcpyAsync(ctx->h_det_xy, ctx->d_det_xy, nxy, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipMemcpyAsync(ctx->h_det_score, ctx->d_det_score, nxy, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipMemcpyAsync(ctx->h_det_count, ctx->d_det_count, (size_t)n_cells * 4, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipMemcpyAsync(ctx->h_det_count + MAX_CELLS, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->s_front));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    REQ((ctx->h_det_count[MAX_CELLS] & 2) == 0, PMV_ERR_OVERFLOW, "pmv_detect_shitomasi: candidate list overflow");
+    memcpy(out_xy, ctx->h_det_xy, nxy);
+    memcpy(out_score, ctx->h_det_score, nxy);
+    memcpy(out_count, ctx->h_det_count, (size_t)n_cells * 4);
+    return PMV_OK;
+}
+
+int pmv_debug_gftt_response(pmv_ctx* ctx, int slot, const int* cell, float* out) {
+    int rc = check_cells(ctx, slot, cell, 1, 1);
+    if (rc) return rc;
+    REQ(out, PMV_ERR_INVALID, "null output");
+    int xy[2], cnt;
+    rc = pmv_detect_gftt(ctx, slot, cell, 1, 1, 0.01, 5.0, xy, &cnt);
+    if (rc) return rc;
+    CKC(hipMemcpy(out, ctx->d_eig, (size_t)cell[2] * cell[3] * sizeof(float), hipMemcpyDeviceToHost));
+    return PMV_OK;
+}
+
+int pmv_debug_shitomasi_response(pmv_ctx* ctx, int slot, const int* cell, double* out) {
+    int rc = check_cells(ctx, slot, cell, 1, 1);
+    if (rc) return rc;
+    REQ(out, PMV_ERR_INVALID, "null output");
+    int xy[2], cnt; double sc;
+    rc = pmv_detect_shitomasi(ctx, slot, cell, 1, 1, 0.4, xy, &sc, &cnt);
+    if (rc) return rc;
+    CKC(hipMemcpy(out, ctx->d_eig, (size_t)cell[2] * cell[3] * sizeof(double), hipMemcpyDeviceToHost));
+    return PMV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,595 @@
+// gfx950 front-end kernels: padded pyramid build, per-track pyramidal Lucas–Kanade, fused corner detectors.
+// Replaces the OpenCV calls behind BaseFeatureMatcher / BaseFeatureExtractor (see include/pmv_hip.h for file:line).
+// All integer results (track coordinates after truncation, status bytes, corner lists) are bit-exact with oracle/:
+//   * LK: every window sum is an exact integer (per-lane int32 partials, 64-bit wave reduction), rounded once to f32;
+//   * GFTT: float32 ops in a fixed order, compiled with -ffp-contract=off; the 3x3 box sum is a 9-term double sum.
+#include "pmv_device.h"
+#include <float.h>
+
+namespace pmv {
+
+// =========================================================================================================
+// Pyramid
+// =========================================================================================================
+// level 0: tight gray frame -> padded REFLECT_101 buffer. One thread writes 4 horizontally adjacent bytes.
+__global__ __launch_bounds__(256) void k_pad_level0(uint8_t* slots, PyrLayout L, int first_slot) {
+    uint8_t* slot = slots + (size_t)(first_slot + blockIdx.z) * L.slot_bytes;
+    const uint8_t* src = slot + L.gray_off;
+    const int w = L.w[0], h = L.h[0], stride = L.stride[0];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;   // padded x
+    const int py = blockIdx.y;                              // padded y
+    if (x4 >= w + 2 * PAD) return;
+    const int sy = reflect101(py - PAD, h);
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int sx = reflect101(x4 + k - PAD, w);
+        v |= (uint32_t)src[(size_t)sy * w + sx] << (8 * k);
+    }
+    *(uint32_t*)(slot + L.off[0] + (size_t)py * stride + x4) = v;
+}
+
+// level l-1 (padded) -> level l (padded): cv::pyrDown [1 4 6 4 1]^2, (sum+128)>>8; padding pixels are computed
+// directly as the pyrDown value at the REFLECT_101-mapped coordinate, so one pass writes interior and border.
+__global__ __launch_bounds__(256) void k_pyrdown(uint8_t* slots, PyrLayout L, int ld, int first_slot) {
+    uint8_t* slot = slots + (size_t)(first_slot + blockIdx.z) * L.slot_bytes;
+    const int ls = ld - 1;
+    const uint8_t* src = level_origin((const uint8_t*)slot, L, ls);
+    const int ss = L.stride[ls];
+    const int dw = L.w[ld], dh = L.h[ld], ds = L.stride[ld];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int py = blockIdx.y;
+    if (x4 >= dw + 2 * PAD) return;
+    const int ry = reflect101(py - PAD, dh);
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int rx = reflect101(x4 + k - PAD, dw);
+        const uint8_t* p = src + (size_t)(2 * ry - 2) * ss + (2 * rx - 2);
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int ki = (i == 0 || i == 4) ? 1 : ((i == 2) ? 6 : 4);
+            const uint8_t* r = p + (size_t)i * ss;
+            acc += ki * (r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2]);
+        }
+        v |= (uint32_t)((acc + 128) >> 8) << (8 * k);
+    }
+    *(uint32_t*)(slot + L.off[ld] + (size_t)py * ds + x4) = v;
+}
+
+hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n) {
+    dim3 grid((L.w[0] + 2 * PAD + 1023) / 1024, L.h[0] + 2 * PAD, n);
+    hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, s, slots, L, first_slot);
+    return hipGetLastError();
+}
+hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int ld, int first_slot, int n) {
+    dim3 grid((L.w[ld] + 2 * PAD + 1023) / 1024, L.h[ld] + 2 * PAD, n);
+    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, slots, L, ld, first_slot);
+    return hipGetLastError();
+}
+
+// =========================================================================================================
+// Pyramidal Lucas–Kanade: one wavefront per track, all levels inside one launch.
+//   lane l owns window row (l>>1), columns (l&1)*16 .. +15; its 16 (I, Ix, Iy) samples live in registers.
+//   LDS per wave: 35x35 u8 tile of the previous image (-> Scharr on the fly, no derivative image in HBM),
+//   33x33 (dx,dy) int16 pairs, and a 64x64 u8 search tile of the next image that is re-staged only when the
+//   window walks out of it.
+// =========================================================================================================
+constexpr int SI_STRIDE = 40;
+constexpr int SD_STRIDE = 33;
+constexpr int SJ_STRIDE = 68;
+
+__device__ inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ inline void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+    w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+    w01 = __float2int_rn(a * (1.f - b) * 16384.f);
+    w10 = __float2int_rn((1.f - a) * b * 16384.f);
+    w11 = 16384 - w00 - w01 - w10;
+}
+
+__device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0, int ty0, int lane) {
+    // lane = tile row; 64 bytes per row, dword-aligned (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0)
+    const uint32_t* g = (const uint32_t*)(Jorg + (ptrdiff_t)(ty0 + lane) * js + tx0);
+    uint32_t* d = (uint32_t*)(sJ + lane * SJ_STRIDE);
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = g[k];
+}
+
+__global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS,
+                                           PyrLayout L, const float* __restrict__ prev_xy, int n, LKParams P,
+                                           float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
+                                           float* __restrict__ out_err) {
+    __shared__ __attribute__((aligned(16))) uint8_t sI[35 * SI_STRIDE];
+    __shared__ __attribute__((aligned(16))) short2 sD[33 * SD_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t sJ[64 * SJ_STRIDE];
+    const int t = blockIdx.x;
+    if (t >= n) return;
+    const int lane = threadIdx.x;
+    const int r = lane >> 1, c0 = (lane & 1) * 16;
+    const float px0 = prev_xy[2 * t], py0 = prev_xy[2 * t + 1];
+    const int W = LK_WIN;
+    const float half = 15.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    float outx = 0.f, outy = 0.f, err = 0.f;
+    int status = 1;
+    const int ml = L.n_levels - 1;
+
+    for (int level = ml; level >= 0; level--) {
+        const int lw = L.w[level], lh = L.h[level], ls = L.stride[level];
+        const uint8_t* Iorg = level_origin(prevS, L, level);
+        const uint8_t* Jorg = level_origin(nextS, L, level);
+        const float lscale = (float)(1. / (1 << level));
+        float prevx = px0 * lscale, prevy = py0 * lscale;
+        float nx, ny;
+        if (level == ml) { nx = prevx; ny = prevy; }
+        else { nx = outx * 2.f; ny = outy * 2.f; }
+        outx = nx; outy = ny;
+        prevx -= half; prevy -= half;
+        const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+        if (ipx < -W || ipx >= lw || ipy < -W || ipy >= lh) {
+            if (level == 0) { status = 0; err = 0.f; }
+            continue;
+        }
+        int iw00, iw01, iw10, iw11;
+        bilinear_weights(prevx - ipx, prevy - ipy, iw00, iw01, iw10, iw11);
+
+        __syncthreads();
+        // ---- stage the 35x35 I tile: rows ipy-1 .. ipy+33, cols ipx-1 .. ipx+33 (always inside the padded buffer)
+        for (int idx = lane; idx < 35 * 35; idx += 64) {
+            const int y = idx / 35, x = idx - y * 35;
+            sI[y * SI_STRIDE + x] = Iorg[(ptrdiff_t)(ipy - 1 + y) * ls + (ipx - 1 + x)];
+        }
+        __syncthreads();
+        // ---- Scharr (calcSharrDeriv) at the 33x33 sample positions; constant 0 outside the image
+        for (int idx = lane; idx < 33 * 33; idx += 64) {
+            const int y = idx / 33, x = idx - y * 33;
+            const uint8_t* c = &sI[(y + 1) * SI_STRIDE + (x + 1)];
+            const int gx = ipx + x, gy = ipy + y;
+            short2 d = make_short2(0, 0);
+            if (gx >= 0 && gx < lw && gy >= 0 && gy < lh) {
+                const int t0m = (c[-SI_STRIDE - 1] + c[SI_STRIDE - 1]) * 3 + c[-1] * 10;
+                const int t0p = (c[-SI_STRIDE + 1] + c[SI_STRIDE + 1]) * 3 + c[1] * 10;
+                const int t1m = c[SI_STRIDE - 1] - c[-SI_STRIDE - 1];
+                const int t1c = c[SI_STRIDE] - c[-SI_STRIDE];
+                const int t1p = c[SI_STRIDE + 1] - c[-SI_STRIDE + 1];
+                d.x = (short)(t0p - t0m);
+                d.y = (short)((t1p + t1m) * 3 + t1c * 10);
+            }
+            sD[y * SD_STRIDE + x] = d;
+        }
+        __syncthreads();
+        // ---- this lane's 16 window samples (I with 5 fractional bits, Ix, Iy) + exact A sums
+        int Iv[16], Ix[16], Iy[16];
+        int a11 = 0, a12 = 0, a22 = 0;   // per-lane partials fit int32: 16 * 4080^2 < 2^31
+        {
+            const uint8_t* i0 = &sI[(r + 1) * SI_STRIDE + (c0 + 1)];
+            const short2* d0 = &sD[r * SD_STRIDE + c0];
+            int p0 = i0[0], p1 = i0[SI_STRIDE];
+            short2 q0 = d0[0], q1 = d0[SD_STRIDE];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int p0n = i0[k + 1], p1n = i0[SI_STRIDE + k + 1];
+                const short2 q0n = d0[k + 1], q1n = d0[SD_STRIDE + k + 1];
+                Iv[k] = descale(p0 * iw00 + p0n * iw01 + p1 * iw10 + p1n * iw11, 9);
+                const int ixv = descale(q0.x * iw00 + q0n.x * iw01 + q1.x * iw10 + q1n.x * iw11, 14);
+                const int iyv = descale(q0.y * iw00 + q0n.y * iw01 + q1.y * iw10 + q1n.y * iw11, 14);
+                Ix[k] = ixv; Iy[k] = iyv;
+                a11 += ixv * ixv; a12 += ixv * iyv; a22 += iyv * iyv;
+                p0 = p0n; p1 = p1n; q0 = q0n; q1 = q1n;
+            }
+        }
+        const long long sA11 = wave_sum_i64(a11), sA12 = wave_sum_i64(a12), sA22 = wave_sum_i64(a22);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * W * W);
+        if (minEig < P.min_eig || D < FLT_EPSILON) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        int tx0 = 0, ty0 = 0;
+        bool have_tile = false;
+
+        for (int j = 0; j < P.max_iter; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -W || inx >= lw || iny < -W || iny >= lh) {
+                if (level == 0) status = 0;
+                break;
+            }
+            int wx = inx - tx0, wy = iny - ty0;
+            if (!have_tile || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
+                tx0 = (inx - 16) & ~3; ty0 = iny - 16;
+                __syncthreads();
+                stage_J(sJ, Jorg, ls, tx0, ty0, lane);
+                __syncthreads();
+                have_tile = true;
+                wx = inx - tx0; wy = iny - ty0;
+            }
+            bilinear_weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
+            int b1 = 0, b2 = 0;          // per-lane partials fit int32: 16 * 8160 * 4080 < 2^31
+            {
+                const uint8_t* j0 = &sJ[(wy + r) * SJ_STRIDE + wx + c0];
+                int p0 = j0[0], p1 = j0[SJ_STRIDE];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
+                    const int diff = descale(p0 * iw00 + p0n * iw01 + p1 * iw10 + p1n * iw11, 9) - Iv[k];
+                    b1 += diff * Ix[k]; b2 += diff * Iy[k];
+                    p0 = p0n; p1 = p1n;
+                }
+            }
+            const float fb1 = (float)wave_sum_i64(b1) * FLT_SCALE, fb2 = (float)wave_sum_i64(b2) * FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * D;
+            const float dy = (A12 * fb1 - A11 * fb2) * D;
+            nx += dx; ny += dy;
+            outx = nx + half; outy = ny + half;
+            if ((double)dx * dx + (double)dy * dy <= P.eps2d) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+
+        if (status && level == 0) {
+            const float fx = outx - half, fy = outy - half;
+            const int inx = (int)floorf(fx), iny = (int)floorf(fy);
+            if (inx < -W || inx >= lw || iny < -W || iny >= lh) {
+                status = 0;
+            } else {
+                int wx = inx - tx0, wy = iny - ty0;
+                if (!have_tile || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
+                    tx0 = (inx - 16) & ~3; ty0 = iny - 16;
+                    __syncthreads();
+                    stage_J(sJ, Jorg, ls, tx0, ty0, lane);
+                    __syncthreads();
+                    wx = inx - tx0; wy = iny - ty0;
+                }
+                bilinear_weights(fx - inx, fy - iny, iw00, iw01, iw10, iw11);
+                int e = 0;
+                const uint8_t* j0 = &sJ[(wy + r) * SJ_STRIDE + wx + c0];
+                int p0 = j0[0], p1 = j0[SJ_STRIDE];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
+                    const int diff = descale(p0 * iw00 + p0n * iw01 + p1 * iw10 + p1n * iw11, 9) - Iv[k];
+                    e += diff < 0 ? -diff : diff;
+                    p0 = p0n; p1 = p1n;
+                }
+                err = (float)wave_sum_i64(e) * (1.f / (32 * W * W));
+            }
+        }
+    }
+    if (lane == 0) {
+        out_xy[2 * t] = outx; out_xy[2 * t + 1] = outy;
+        out_status[t] = (uint8_t)status;
+        out_err[t] = err;
+    }
+}
+
+hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
+                     const float* d_prev_xy, int n, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lk, dim3(n), dim3(64), 0, s, prev_slot, next_slot, L, d_prev_xy, n, P, d_out_xy, d_status, d_err);
+    return hipGetLastError();
+}
+
+// =========================================================================================================
+// goodFeaturesToTrack per grid cell
+// =========================================================================================================
+__device__ inline unsigned f32_key(float v) {   // order-preserving map float -> uint32
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ inline float f32_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ inline unsigned long long f64_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ inline double f64_unkey(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
+// Phase 1: min-eigenvalue response, 32x32 outputs per 256-thread workgroup.
+// grid = (tiles_x, tiles_y, n_cells). cov at the 34x34 halo positions is evaluated at the REFLECT_101-mapped CELL
+// coordinate (box filter border = cell), from pixels of the PARENT image with REFLECT_101 on the parent (Sobel border).
+__global__ __launch_bounds__(256) void k_gftt_eig(const uint8_t* __restrict__ slot, PyrLayout L,
+                                                  const int* __restrict__ cells, float* __restrict__ eig,
+                                                  unsigned* __restrict__ cellmax) {
+    __shared__ float sC[34 * 34 * 3];
+    __shared__ unsigned smax[4];
+    const int cell = blockIdx.z;
+    const int cx0 = cells[4 * cell], cy0 = cells[4 * cell + 1], cw = cells[4 * cell + 2], ch = cells[4 * cell + 3];
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+    if (tx0 >= cw || ty0 >= ch) return;
+    const uint8_t* img = level_origin(slot, L, 0);
+    const int st = L.stride[0];
+    const float k1 = (float)(1.0 / 3060.0), k2 = (float)(2.0 / 3060.0);
+    for (int idx = threadIdx.x; idx < 34 * 34; idx += 256) {
+        const int hy = idx / 34, hx = idx - hy * 34;
+        const int lx = reflect101(tx0 - 1 + hx, cw), ly = reflect101(ty0 - 1 + hy, ch);
+        // padded level 0 == REFLECT_101 of the parent image, so +-1 neighbours are plain loads
+        const uint8_t* p = img + (ptrdiff_t)(cy0 + ly) * st + (cx0 + lx);
+        const float p00 = p[-st - 1], p01 = p[-st], p02 = p[-st + 1];
+        const float p10 = p[-1], p12 = p[1];
+        const float p20 = p[st - 1], p21 = p[st], p22 = p[st + 1];
+        const float rt = p02 - p00, rm = p12 - p10, rb = p22 - p20;
+        const float dx = (rt + rb) * k1 + rm * k2;
+        float s_t = k1 * p00; s_t += k2 * p01; s_t += k1 * p02;
+        float s_b = k1 * p20; s_b += k2 * p21; s_b += k1 * p22;
+        const float dy = s_b - s_t;
+        sC[idx * 3 + 0] = dx * dx; sC[idx * 3 + 1] = dx * dy; sC[idx * 3 + 2] = dy * dy;
+    }
+    __syncthreads();
+    unsigned mk = 0;   // key 0 is below every real float key
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+        const int oy = idx >> 5, ox = idx & 31;
+        const int x = tx0 + ox, y = ty0 + oy;
+        if (x >= cw || y >= ch) continue;
+        double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const float* c = &sC[((oy + j) * 34 + (ox + i)) * 3];
+                s0 += c[0]; s1 += c[1]; s2 += c[2];
+            }
+        const float a = (float)s0 * 0.5f, b = (float)s1, c2 = (float)s2 * 0.5f;
+        const float e = (a + c2) - sqrtf((a - c2) * (a - c2) + b * b);
+        eig[(size_t)cell * CELL_PIX + y * cw + x] = e;
+        if (e == e) { const unsigned k = f32_key(e); mk = k > mk ? k : mk; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(mk, o, 64); mk = t > mk ? t : mk; }
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = smax[0];
+        for (int i = 1; i < 4; i++) m = smax[i] > m ? smax[i] : m;
+        atomicMax(&cellmax[cell], m);
+    }
+}
+
+// Phase 2: threshold (TOZERO at quality*max), 3x3 NMS, then greedy min-distance selection in descending
+// (value, address) order. The sequential OpenCV loop "walk the sorted list, accept a corner unless an accepted one is
+// closer than minDistance" is evaluated as: repeat {arg-max over live candidates; accept; kill every candidate closer
+// than minDistance} — identical result, max_corners rounds, no sort.
+constexpr int GFTT_CAP = 16384;
+__global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ cells, const float* __restrict__ eig,
+                                                      const unsigned* __restrict__ cellmax, int max_corners,
+                                                      double quality, double min_dist, int* __restrict__ out_xy,
+                                                      int* __restrict__ out_count, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* cval = (float*)smem;                       // GFTT_CAP
+    unsigned* cidx = (unsigned*)(smem + GFTT_CAP * 4); // GFTT_CAP
+    unsigned long long* wbest = (unsigned long long*)(smem + GFTT_CAP * 8);  // 16
+    int* scount = (int*)(smem + GFTT_CAP * 8 + 16 * 8);
+    const int cell = blockIdx.x;
+    const int cw = cells[4 * cell + 2], ch = cells[4 * cell + 3];
+    const float* E = eig + (size_t)cell * CELL_PIX;
+    const int tid = threadIdx.x;
+    if (tid == 0) *scount = 0;
+    __syncthreads();
+    const double maxVal = (double)f32_unkey(cellmax[cell]);
+    const float thr = (float)(maxVal * quality);
+    const int iw = cw - 2, ih = ch - 2;
+    for (int idx = tid; idx < iw * ih; idx += 1024) {
+        const int y = idx / iw + 1, x = idx - (y - 1) * iw + 1;
+        const float raw = E[y * cw + x];
+        const float v = raw > thr ? raw : 0.f;
+        if (v == 0.f) continue;
+        bool ismax = true;
+#pragma unroll
+        for (int j = -1; j <= 1; j++)
+#pragma unroll
+            for (int i = -1; i <= 1; i++) {
+                const float nr = E[(y + j) * cw + x + i];
+                const float nv = nr > thr ? nr : 0.f;
+                ismax = ismax && !(nv > v);
+            }
+        if (ismax) {
+            const int slot = atomicAdd(scount, 1);
+            if (slot < GFTT_CAP) { cval[slot] = v; cidx[slot] = (unsigned)(y * cw + x); }
+        }
+    }
+    __syncthreads();
+    int ncand = *scount;
+    if (ncand > GFTT_CAP) { if (tid == 0) atomicOr(flags, 1); ncand = GFTT_CAP; }
+    const bool use_dist = min_dist >= 1.0;
+    const double md2 = min_dist * min_dist;
+    int naccepted = 0;
+    for (int it = 0; it < max_corners; it++) {
+        unsigned long long best = 0;
+        for (int i = tid; i < ncand; i += 1024) {
+            const float v = cval[i];
+            if (v > 0.f) {   // dead candidates are marked with -1
+                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | cidx[i];
+                best = key > best ? key : best;
+            }
+        }
+        best = wave_max_u64(best);
+        if ((tid & 63) == 0) wbest[tid >> 6] = best;
+        __syncthreads();
+        unsigned long long b = wbest[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) b = wbest[i] > b ? wbest[i] : b;
+        if (b == 0) break;
+        const int bidx = (int)(b & 0xffffffffu);
+        const int by = bidx / cw, bx = bidx - by * cw;
+        if (tid == 0) {
+            out_xy[((size_t)cell * max_corners + naccepted) * 2] = bx;
+            out_xy[((size_t)cell * max_corners + naccepted) * 2 + 1] = by;
+        }
+        naccepted++;
+        for (int i = tid; i < ncand; i += 1024) {
+            if (cval[i] <= 0.f) continue;
+            const int ci = (int)cidx[i];
+            if (use_dist) {
+                const int y = ci / cw, x = ci - y * cw;
+                const int dx = x - bx, dy = y - by;
+                if ((double)(dx * dx + dy * dy) < md2) cval[i] = -1.f;
+            } else if (ci == bidx) cval[i] = -1.f;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out_count[cell] = naccepted;
+}
+
+hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
+                       int max_per_cell, double quality, double min_dist, float* d_eig, unsigned* d_cellmax,
+                       int* d_out_xy, int* d_out_count, int* d_flags) {
+    hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned) * n_cells, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gftt_eig, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_eig, d_cellmax);
+    const size_t shm = GFTT_CAP * 8 + 16 * 8 + 16;
+    hipLaunchKernelGGL(k_gftt_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_eig, d_cellmax, max_per_cell,
+                       quality, min_dist, d_out_xy, d_out_count, d_flags);
+    return hipGetLastError();
+}
+
+// =========================================================================================================
+// ShiTomasiFeatureExtractor (in-repo arithmetic, float64)
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_st_resp(const uint8_t* __restrict__ slot, PyrLayout L,
+                                                 const int* __restrict__ cells, double* __restrict__ resp,
+                                                 unsigned long long* __restrict__ cellmax) {
+    __shared__ double sH[34 * 34 * 3];
+    __shared__ unsigned long long smax[4];
+    const int cell = blockIdx.z;
+    const int cx0 = cells[4 * cell], cy0 = cells[4 * cell + 1], cw = cells[4 * cell + 2], ch = cells[4 * cell + 3];
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+    if (tx0 >= cw || ty0 >= ch) return;
+    const uint8_t* img = level_origin(slot, L, 0);
+    const int st = L.stride[0];
+    for (int idx = threadIdx.x; idx < 34 * 34; idx += 256) {
+        const int hy = idx / 34, hx = idx - hy * 34;
+        const int lx = reflect101(tx0 - 1 + hx, cw), ly = reflect101(ty0 - 1 + hy, ch);
+        double gx = 0.0, gy = 0.0;   // Frame.cpp:58-86: zero on the cell border
+        if (lx >= 1 && lx < cw - 1 && ly >= 1 && ly < ch - 1) {
+            const uint8_t* p = img + (ptrdiff_t)(cy0 + ly) * st + (cx0 + lx);
+            gx = 1. / 2. * (double)(int8_t)p[1] - 1. / 2. * (double)(int8_t)p[-1];     // quirk Q1: signed char view
+            gy = 1. / 2. * (double)(int8_t)p[st] - 1. / 2. * (double)(int8_t)p[-st];
+        }
+        sH[idx * 3 + 0] = gx * gx; sH[idx * 3 + 1] = gy * gy; sH[idx * 3 + 2] = gx * gy;
+    }
+    __syncthreads();
+    unsigned long long mk = 0;
+    const double inv9 = 1.0 / 9.0;
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+        const int oy = idx >> 5, ox = idx & 31;
+        const int x = tx0 + ox, y = ty0 + oy;
+        if (x >= cw || y >= ch) continue;
+        double R = 0.0;
+        if (x < cw - 1) {   // ShiTomasiFeatureExtractor.cpp:58 skips the last column
+            double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const double* h = &sH[((oy + j) * 34 + (ox + i)) * 3];
+                    s0 += h[0]; s1 += h[1]; s2 += h[2];
+                }
+            const double Ixx = s0 * inv9, Iyy = s1 * inv9, Ixy = s2 * inv9;
+            const double B = -Ixx - Iyy;
+            const double C = Ixx * Iyy - Ixy * Ixy;
+            const double disc = sqrt(B * B - 4 * C);
+            const double l1 = (-B + disc) / 2, l2 = (-B - disc) / 2;
+            R = (l2 < l1) ? l2 : l1;   // std::min(l1, l2)
+        }
+        resp[(size_t)cell * CELL_PIX + y * cw + x] = R;
+        if (R == R) { const unsigned long long k = f64_key(R); mk = k > mk ? k : mk; }
+    }
+    mk = wave_max_u64(mk);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = smax[0];
+        for (int i = 1; i < 4; i++) m = smax[i] > m ? smax[i] : m;
+        atomicMax(&cellmax[cell], m);
+    }
+}
+
+constexpr int ST_CAP = 8192;
+__global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cells, const double* __restrict__ resp,
+                                                    const unsigned long long* __restrict__ cellmax, int max_feats,
+                                                    double quality, int* __restrict__ out_xy,
+                                                    double* __restrict__ out_score, int* __restrict__ out_count,
+                                                    int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* ckey = (unsigned long long*)smem;              // ST_CAP: ordered score key, 0 = dead
+    unsigned* cidx = (unsigned*)(smem + ST_CAP * 8);                   // ST_CAP
+    unsigned long long* wk = (unsigned long long*)(smem + ST_CAP * 12);// 16
+    unsigned* wi = (unsigned*)(smem + ST_CAP * 12 + 16 * 8);           // 16
+    int* scount = (int*)(smem + ST_CAP * 12 + 16 * 12);
+    const int cell = blockIdx.x;
+    const int cw = cells[4 * cell + 2], ch = cells[4 * cell + 3];
+    const double* R = resp + (size_t)cell * CELL_PIX;
+    const int tid = threadIdx.x;
+    if (tid == 0) *scount = 0;
+    __syncthreads();
+    const double rmax = f64_unkey(cellmax[cell]);
+    const double thr = rmax * quality;
+    for (int idx = tid; idx < cw * ch; idx += 1024) {
+        const double v = R[idx];
+        if (v > thr) {
+            const int slot = atomicAdd(scount, 1);
+            if (slot < ST_CAP) { ckey[slot] = f64_key(v); cidx[slot] = (unsigned)idx; }
+        }
+    }
+    __syncthreads();
+    int ncand = *scount;
+    if (ncand > ST_CAP) { if (tid == 0) atomicOr(flags, 2); ncand = ST_CAP; }
+    int nacc = 0;
+    for (int it = 0; it < max_feats; it++) {
+        // best = highest score, ties -> lowest raster index (stable sort of a raster-ordered list)
+        unsigned long long bk = 0; unsigned bi = 0xffffffffu;
+        for (int i = tid; i < ncand; i += 1024) {
+            const unsigned long long k = ckey[i];
+            const unsigned ci = cidx[i];
+            if (k > bk || (k == bk && k != 0 && ci < bi)) { bk = k; bi = ci; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long tk = __shfl_xor(bk, o, 64);
+            const unsigned ti = __shfl_xor(bi, o, 64);
+            if (tk > bk || (tk == bk && ti < bi)) { bk = tk; bi = ti; }
+        }
+        if ((tid & 63) == 0) { wk[tid >> 6] = bk; wi[tid >> 6] = bi; }
+        __syncthreads();
+        bk = wk[0]; bi = wi[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++)
+            if (wk[i] > bk || (wk[i] == bk && wi[i] < bi)) { bk = wk[i]; bi = wi[i]; }
+        if (bk == 0) break;
+        if (tid == 0) {
+            out_xy[((size_t)cell * max_feats + nacc) * 2] = (int)(bi % (unsigned)cw);
+            out_xy[((size_t)cell * max_feats + nacc) * 2 + 1] = (int)(bi / (unsigned)cw);
+            out_score[(size_t)cell * max_feats + nacc] = f64_unkey(bk);
+        }
+        nacc++;
+        for (int i = tid; i < ncand; i += 1024)
+            if (cidx[i] == bi) ckey[i] = 0;
+        __syncthreads();
+    }
+    if (tid == 0) out_count[cell] = nacc;
+}
+
+hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
+                            int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,
+                            int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags) {
+    hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned long long) * n_cells, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_st_resp, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_resp, d_cellmax);
+    const size_t shm = ST_CAP * 12 + 16 * 12 + 16;
+    hipLaunchKernelGGL(k_st_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_resp, d_cellmax, max_per_cell,
+                       quality, d_out_xy, d_out_score, d_out_count, d_flags);
+    return hipGetLastError();
+}
+
+}  // namespace pmv

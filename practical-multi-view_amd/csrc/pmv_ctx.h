@@ -1,0 +1,42 @@
+// Internal context definition shared by the C-ABI translation units.
+#pragma once
+#include "pmv_device.h"
+#include "../../include/pmv_hip.h"
+#include <vector>
+
+namespace pmv {
+constexpr int MAX_CELLS = 64;       // 1920x1080 -> 8x5 = 40 cells of 255x255
+constexpr int MAX_PER_CELL = 512;
+struct BackendBuffers;              // PnP / BA device workspaces (backend.hip)
+}
+
+struct pmv_ctx {
+    int device = 0;
+    int max_w = 0, max_h = 0, n_slots = 0, max_tracks = 0, max_ba_cams = 0, max_ba_points = 0, max_ba_obs = 0;
+    hipStream_t s_front = nullptr, s_back = nullptr;
+    pmv::PyrLayout cap;                       // geometry of the largest frame; cap.slot_bytes = slot pitch
+    std::vector<pmv::PyrLayout> slot_layout;  // per slot: n_levels 0 = empty, <0 = staged only, >0 = pyramid built
+    uint8_t* d_slots = nullptr;
+    // LK
+    float *d_prev_xy = nullptr, *d_out_xy = nullptr, *d_err = nullptr;
+    uint8_t* d_status = nullptr;
+    float *h_prev_xy = nullptr, *h_out_xy = nullptr, *h_err = nullptr;
+    uint8_t* h_status = nullptr;
+    // detectors
+    int* d_cells = nullptr;
+    double* d_eig = nullptr;
+    void* d_cellmax = nullptr;
+    int *d_det_xy = nullptr, *d_det_count = nullptr, *d_flags = nullptr;
+    double* d_det_score = nullptr;
+    int *h_det_xy = nullptr, *h_det_count = nullptr;
+    double* h_det_score = nullptr;
+    pmv::BackendBuffers* be = nullptr;
+    char err[512] = "";
+};
+
+namespace pmv {
+void set_err(pmv_ctx* c, const char* fmt, ...);
+PyrLayout make_layout(int w, int h);
+int backend_create(pmv_ctx* c);     // allocates PnP/BA workspaces
+void backend_destroy(pmv_ctx* c);
+}

@@ -1,0 +1,80 @@
+// Shared declarations for the gfx950 kernels of the VO hot path (internal; the public boundary is include/pmv_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pmv {
+
+// ---- frame slot layout in HBM -------------------------------------------------------------------------
+// Every pyramid level is stored with a PAD-pixel BORDER_REFLECT_101 frame on all four sides (cv::buildOpticalFlowPyramid
+// pads by winSize=32; we pad by 64 so that the 64x64 LDS search tile of the LK kernel never leaves the buffer) and a
+// row stride that is a multiple of 64 bytes, so every tile row starts dword-aligned and no kernel needs a border branch.
+constexpr int PAD = 64;
+constexpr int MAX_LEVELS = 5;   // maxLevel 4 -> levels 0..4
+constexpr int LK_WIN = 32;
+
+struct PyrLayout {
+    int n_levels;                 // levels actually built = maxLevel + 1
+    int w[MAX_LEVELS], h[MAX_LEVELS], stride[MAX_LEVELS];
+    uint32_t off[MAX_LEVELS];     // byte offset of the padded level buffer inside the slot
+    uint32_t gray_off;            // byte offset of the staged tight gray frame (w0*h0 bytes)
+    uint32_t slot_bytes;
+};
+
+__host__ __device__ inline int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+// pointer to pixel (0,0) of a padded level
+__host__ __device__ inline const uint8_t* level_origin(const uint8_t* slot, const PyrLayout& L, int l) {
+    return slot + L.off[l] + (size_t)PAD * L.stride[l] + PAD;
+}
+__host__ __device__ inline uint8_t* level_origin(uint8_t* slot, const PyrLayout& L, int l) {
+    return slot + L.off[l] + (size_t)PAD * L.stride[l] + PAD;
+}
+
+// ---- wave64 helpers -------------------------------------------------------------------------------------
+__device__ inline long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// ---- launch entry points (frontend.hip) -------------------------------------------------------------------
+struct LKParams {
+    int max_iter;     // 30
+    float eps2;       // not used in float: see eps2d
+    double eps2d;     // epsilon^2 = 1e-4
+    float min_eig;    // 1e-4
+};
+
+hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n);
+hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int level_dst, int first_slot, int n);
+hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
+                     const float* d_prev_xy, int n, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err);
+
+// GFTT: eig maps (n_cells * 255*255 floats), cell max (n_cells uint32 ordered keys), outputs
+hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
+                       int max_per_cell, double quality, double min_dist, float* d_eig, unsigned* d_cellmax,
+                       int* d_out_xy, int* d_out_count, int* d_flags);
+hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
+                            int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,
+                            int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags);
+
+constexpr int CELL_MAX = 255;                 // OdometryPipeline.h:31 grid_size
+constexpr int CELL_PIX = CELL_MAX * CELL_MAX;
+
+}  // namespace pmv

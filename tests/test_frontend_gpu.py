@@ -1,0 +1,173 @@
+"""GPU parity (through the C ABI) of the front-end kernels against the oracle: pyramid bytes, GFTT / ShiTomasi corner
+lists and response maps, LK positions/status/err.  Bar: bit-exact (integer / index work and fixed-order float32)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KITTI07 = dict(w=1226, h=370, fx=707.0912, fy=707.0912, cx=601.8873, cy=183.1104)
+KITTI00 = dict(w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157)
+
+
+def _frames(pmv, cfg, n, seed=1007, first=0):
+    f, _ = pmv.synth_sequence(seed, first, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"])
+    return f
+
+
+@pytest.mark.parametrize("cfg", [KITTI07, KITTI00, dict(w=321, h=163, fx=200., fy=200., cx=160., cy=80.)])
+def test_pyramid_matches_oracle(pmv, orc, gpu_ctx_factory, cfg):
+    fr = _frames(pmv, cfg, 1)[0]
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=1)
+    ctx.frame_upload(0, fr)
+    nl = ctx.num_levels(0)
+    ref = fr
+    for l in range(nl + 1):
+        got = ctx.get_level(0, l, cfg["w"], cfg["h"])
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), f"level {l} differs"
+        ref = orc.pyr_down(ref)
+    # level-count rule of buildOpticalFlowPyramid: next level would be <= 32 in a dimension
+    assert min(ref.shape) <= 32 or nl == 4
+
+
+def test_batched_build_equals_single_upload(pmv, gpu_ctx_factory):
+    cfg = KITTI07
+    fr = _frames(pmv, cfg, 3)
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=4)
+    ctx.frames_stage(0, fr)
+    ctx.frames_build(0, 3)
+    ctx.frame_upload(3, fr[2])
+    for l in range(ctx.num_levels(3) + 1):
+        assert np.array_equal(ctx.get_level(2, l, cfg["w"], cfg["h"]), ctx.get_level(3, l, cfg["w"], cfg["h"]))
+
+
+@pytest.mark.parametrize("cfg,per_cell", [(KITTI07, 40), (KITTI00, 80)])
+def test_gftt_matches_oracle(pmv, orc, gpu_ctx_factory, cfg, per_cell):
+    fr = _frames(pmv, cfg, 1, seed=1003)[0]
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=1)
+    ctx.frame_upload(0, fr)
+    cells = pmv.grid_cells(cfg["w"], cfg["h"])
+    assert len(cells) == 10
+    got = ctx.detect_gftt(0, cells, per_cell)
+    for c, g in zip(cells, got):
+        ref, eig = orc.gftt_cell(fr, c, per_cell, want_eig=True)
+        assert np.array_equal(ctx.gftt_response(0, c), eig), "min-eigenvalue map differs"
+        assert np.array_equal(g, ref), f"corner list differs in cell {c}"
+        assert len(g) > 0
+
+
+def test_gftt_edge_cases(pmv, orc, gpu_ctx_factory):
+    w, h = 300, 280
+    rng = np.random.default_rng(5)
+    flat = np.full((h, w), 77, np.uint8)                       # no corners at all
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)       # dense candidates, many near-ties
+    ties = np.zeros((h, w), np.uint8)
+    ties[::16, ::16] = 255                                       # identical responses: tie-break by address
+    ctx = gpu_ctx_factory(w, h, n_slots=1)
+    cells = pmv.grid_cells(w, h)
+    for img in (flat, noise, ties):
+        ctx.frame_upload(0, img)
+        for mx, md in ((40, 5.0), (500, 5.0), (25, 0.5), (30, 11.3)):
+            got = ctx.detect_gftt(0, cells, mx, min_dist=md)
+            for c, g in zip(cells, got):
+                ref = orc.gftt_cell(img, c, mx, min_dist=md)
+                assert np.array_equal(g, ref)
+    small = np.asarray([[7, 9, 3, 3], [0, 0, 5, 4]], np.int32)  # tiny cells
+    got = ctx.detect_gftt(0, small, 10)
+    for c, g in zip(small, got):
+        assert np.array_equal(g, orc.gftt_cell(ties, c, 10))
+
+
+def test_shitomasi_matches_oracle(pmv, orc, gpu_ctx_factory):
+    cfg = KITTI07
+    fr = _frames(pmv, cfg, 1, seed=1001)[0]
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=1)
+    ctx.frame_upload(0, fr)
+    cells = pmv.grid_cells(cfg["w"], cfg["h"])
+    got = ctx.detect_shitomasi(0, cells, 40)
+    for c, (gxy, gsc) in zip(cells, got):
+        rxy, rsc, R = orc.shitomasi_cell(fr, c, 40, want_resp=True)
+        Rg = ctx.shitomasi_response(0, c)
+        assert np.array_equal(np.isnan(Rg), np.isnan(R))
+        assert np.array_equal(np.nan_to_num(Rg), np.nan_to_num(R)), "response differs"
+        assert np.array_equal(gxy, rxy) and np.array_equal(gsc, rsc)
+
+
+def _check_lk(ctx, orc, a, b, pts):
+    xy, st, err = ctx.lk_track(0, 1, pts)
+    rxy, rst, rerr, _ = orc.lk_track(a, b, pts)
+    assert np.array_equal(st, rst)
+    ok = st > 0
+    assert np.array_equal(xy[ok], rxy[ok])       # float32 positions, bit-exact
+    assert np.array_equal(err[ok], rerr[ok])
+    # what the reference keeps: Feature(int(x), int(y)) for status==1 (OpenCVLucasKanadeFM.cpp:25)
+    assert np.array_equal(xy[ok].astype(np.int32), rxy[ok].astype(np.int32))
+    return ok
+
+
+@pytest.mark.parametrize("cfg,per_cell", [(KITTI07, 40), (KITTI00, 80)])
+def test_lk_matches_oracle_on_sequence(pmv, orc, gpu_ctx_factory, cfg, per_cell):
+    fr = _frames(pmv, cfg, 2, seed=1007, first=10)
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=2)
+    ctx.frame_upload(0, fr[0])
+    ctx.frame_upload(1, fr[1])
+    cells = pmv.grid_cells(cfg["w"], cfg["h"])
+    pts = np.concatenate([d + c[:2] for c, d in zip(cells, ctx.detect_gftt(0, cells, per_cell))]).astype(np.float32)
+    ok = _check_lk(ctx, orc, fr[0], fr[1], pts)
+    assert ok.sum() > 0.6 * len(pts)
+
+
+def test_lk_edge_cases(pmv, orc, gpu_ctx_factory):
+    cfg = KITTI07
+    fr = _frames(pmv, cfg, 2, seed=1002, first=3)
+    w, h = cfg["w"], cfg["h"]
+    ctx = gpu_ctx_factory(w, h, n_slots=2)
+    ctx.frame_upload(0, fr[0])
+    ctx.frame_upload(1, fr[1])
+    rng = np.random.default_rng(11)
+    border = np.array([[0, 0], [w - 1, h - 1], [-20.0, 5], [w + 10.0, h + 3.0], [-40, -40], [3, h - 2], [w - 2, 1],
+                       [w + 200.0, 10], [15.5, 15.5], [w - 16.5, h - 16.5]], np.float32)
+    rnd = np.stack([rng.uniform(-30, w + 30, 400), rng.uniform(-30, h + 30, 400)], 1).astype(np.float32)
+    _check_lk(ctx, orc, fr[0], fr[1], np.concatenate([border, rnd]))
+    # empty input
+    xy, st, err = ctx.lk_track(0, 1, np.zeros((0, 2), np.float32))
+    assert len(xy) == 0
+    # textureless image: every track is rejected by the min-eigenvalue test at level 0
+    flat = np.full((h, w), 100, np.uint8)
+    ctx.frame_upload(0, flat)
+    ctx.frame_upload(1, flat)
+    ok = _check_lk(ctx, orc, flat, flat, rnd[:50])
+    assert ok.sum() == 0
+
+
+def test_lk_recovers_known_translation(pmv, gpu_ctx_factory):
+    """KA7: pure integer translation of a textured image is recovered to sub-pixel accuracy (size-independent property)."""
+    cfg = KITTI00
+    base = _frames(pmv, cfg, 1, seed=1009, first=5)[0]
+    dx, dy = 7, -3
+    shifted = np.roll(np.roll(base, dy, 0), dx, 1)
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=2)
+    ctx.frame_upload(0, base)
+    ctx.frame_upload(1, shifted)
+    cells = pmv.grid_cells(cfg["w"], cfg["h"])
+    pts = np.concatenate([d + c[:2] for c, d in zip(cells, ctx.detect_gftt(0, cells, 40))]).astype(np.float32)
+    inner = (pts[:, 0] > 60) & (pts[:, 0] < cfg["w"] - 60) & (pts[:, 1] > 60) & (pts[:, 1] < cfg["h"] - 60)
+    xy, st, _ = ctx.lk_track(0, 1, pts[inner])
+    d = xy[st > 0] - pts[inner][st > 0]
+    assert (st > 0).mean() > 0.95
+    assert np.abs(np.median(d, 0) - [dx, dy]).max() < 0.05
+
+
+def test_error_paths(pmv, gpu_ctx_factory):
+    ctx = gpu_ctx_factory(200, 100, n_slots=1, max_tracks=8)
+    with pytest.raises(pmv.PmvError):
+        ctx.frame_upload(1, np.zeros((100, 200), np.uint8))          # slot out of range
+    with pytest.raises(pmv.PmvError):
+        ctx.frame_upload(0, np.zeros((101, 200), np.uint8))          # larger than capacity
+    with pytest.raises(pmv.PmvError):
+        ctx.lk_track(0, 0, np.zeros((4, 2), np.float32))             # no pyramid yet
+    ctx.frame_upload(0, np.zeros((100, 200), np.uint8))
+    with pytest.raises(pmv.PmvError):
+        ctx.lk_track(0, 0, np.zeros((9, 2), np.float32))             # exceeds max_tracks
+    with pytest.raises(pmv.PmvError):
+        ctx.detect_gftt(0, np.asarray([[0, 0, 256, 50]], np.int32), 10)   # cell wider than 255
