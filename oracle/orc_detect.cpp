@@ -14,7 +14,7 @@
 //     /root/reference/Frame.cpp:58-86 (signed-char central differences, quirk Q1) and Frame.cpp:119-138
 //     (cv::blur 3x3 of the structure tensor, REFLECT_101).  Pinned by in-repo source except cv::blur's
 //     summation order and std::sort's tie order (FIXED: 9-term raster-order sum * (1/9); ties keep raster order).
-#include "orc_common.h"
+#include "orc_api.h"
 #include <cstring>
 #include <cfloat>
 

@@ -13,8 +13,9 @@
 // integer products ix*ix, ix*iy, iy*iy, diff*ix, diff*iy in float32 in a build-dependent order
 // (scalar / SSE2 / NEON differ bitwise).  This restatement accumulates them EXACTLY in int64 and
 // rounds once to float32, which is order-free and therefore reproducible on any device.
-#include "orc_common.h"
+#include "orc_api.h"
 #include <cfloat>
+#include <thread>
 #include <cstring>
 
 namespace orc {
@@ -87,13 +88,6 @@ void scharr_deriv(const Image8& src, std::vector<int16_t>& out) {
 
 static inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
-struct LKParams {
-    int win = 32;
-    int max_level = 4;
-    int max_iter = 30;
-    double eps = 0.01;
-    float min_eig = 1e-4f;
-};
 
 // One pyramid level of LKTrackerInvoker for one point.  pts are level-0 coordinates in/out.
 static void lk_level(const Image8& I, const std::vector<int16_t>& dI, const Image8& J, int level,
@@ -215,7 +209,7 @@ static void lk_level(const Image8& I, const std::vector<int16_t>& dI, const Imag
 }
 
 void lk_track(const Image8& prev, const Image8& next, const float* prev_xy, int n, const LKParams& P,
-              float* out_xy, uint8_t* out_status, float* out_err, int* levels_used) {
+              float* out_xy, uint8_t* out_status, float* out_err, int* levels_used, int nthreads) {
     std::vector<Image8> pp, np;
     int ml = build_pyramid(prev, P.win, P.max_level, pp);
     int ml2 = build_pyramid(next, P.win, P.max_level, np);
@@ -225,8 +219,17 @@ void lk_track(const Image8& prev, const Image8& next, const float* prev_xy, int 
     std::vector<int16_t> dI;
     for (int level = ml; level >= 0; level--) {
         scharr_deriv(pp[level], dI);
-        for (int i = 0; i < n; i++)
-            lk_level(pp[level], dI, np[level], level, ml, P, prev_xy + 2 * i, out_xy + 2 * i, out_status + i, out_err + i);
+        // points are independent (OpenCV: parallel_for_ over points); any split gives identical results
+        auto work = [&](int lo, int hi) {
+            for (int i = lo; i < hi; i++)
+                lk_level(pp[level], dI, np[level], level, ml, P, prev_xy + 2 * i, out_xy + 2 * i, out_status + i, out_err + i);
+        };
+        if (nthreads <= 1 || n < 2 * nthreads) work(0, n);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nthreads; t++) th.emplace_back(work, (int)((long)n * t / nthreads), (int)((long)n * (t + 1) / nthreads));
+            for (auto& x : th) x.join();
+        }
     }
 }
 
@@ -260,7 +263,7 @@ int orc_lk_track(const uint8_t* prev, const uint8_t* next, int w, int h, const f
     orc::LKParams P;
     P.win = win; P.max_level = max_level; P.max_iter = max_iter; P.eps = eps; P.min_eig = min_eig;
     int lv = 0;
-    orc::lk_track(a, b, prev_xy, n, P, out_xy, out_status, out_err, &lv);
+    orc::lk_track(a, b, prev_xy, n, P, out_xy, out_status, out_err, &lv, 1);
     return lv;
 }
 }

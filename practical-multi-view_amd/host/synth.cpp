@@ -98,7 +98,7 @@ void pose_at(uint64_t seed, int frame, Pose& P) {
     P.t[0] = x0 - xa; P.t[1] = 0; P.t[2] = z0 - za;
 }
 
-// world (KITTI-like, x right / y down / z forward): ground y=+1.65, ceiling y=-7, walls x=-6.5 / +7.5
+// world (KITTI-like, x right / y down / z forward): ground y=+1.65, ceiling y=-9, walls x=-9 / +10.5
 void render(uint64_t seed, int frame, int w, int h, double fx, double fy, double cx, double cy, uint8_t* out, int stride) {
     Pose P0, P;
     pose_at(seed, 0, P0);
@@ -117,7 +117,7 @@ void render(uint64_t seed, int frame, int w, int h, double fx, double fy, double
         tw[i] = s;
     }
     struct Plane { int axis; double off; int id; };  // axis 0: x = off, axis 1: y = off
-    const Plane planes[4] = {{1, 1.65, 0}, {1, -7.0, 1}, {0, -6.5, 2}, {0, 7.5, 3}};
+    const Plane planes[4] = {{1, 1.65, 0}, {1, -9.0, 1}, {0, -9.0, 2}, {0, 10.5, 3}};
     for (int v = 0; v < h; v++) {
         for (int u = 0; u < w; u++) {
             const double dcx = (u - cx) / fx, dcy = (v - cy) / fy, dcz = 1.0;

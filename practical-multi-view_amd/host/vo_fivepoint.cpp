@@ -1,0 +1,424 @@
+// Host triangulator (BaseTriangulator role): restates cv::findEssentialMat(p1, p2, K, RANSAC, 0.99, 1.0, mask) +
+// cv::recoverPose(E, p1, p2, K, R, t, HUGE_VAL, mask, tri) as called at /root/reference/OpenCVFivePointTri.cpp:24-26
+// and the adapter logic around them (:5-54).  Runs only at (re-)initialisation, so it stays on the host for now
+// (SURVEY.md §8f "next #1"); the CPU-baseline pipeline and the GPU pipeline share this one implementation.
+// PARITY UNPINNED (OpenCV internals; published algorithm): Nistér five-point solver inside
+// RANSACPointSetRegistrator (RNG((uint64)-1), 5-point samples, <=1000 iterations, Sampson error, threshold 1px/mean focal),
+// degree-10 polynomial rooted by the Durand–Kerner iteration of cv::solvePoly, four-fold (R,t) cheirality test with DLT
+// triangulation.  FIXED CHOICES: null spaces via cyclic-Jacobi eigenvectors of A^T A; the 10x20 constraint matrix is built
+// by explicit polynomial algebra in Nistér's monomial order instead of OpenCV's generated coefficient table.
+#include "vo_pipeline.h"
+#include "vo_math.h"
+#include <cfloat>
+
+namespace vo {
+namespace {
+
+struct RNG {   // cv::RNG (multiply-with-carry)
+    uint64_t state;
+    explicit RNG(uint64_t s) : state(s ? s : 0xffffffffULL) {}
+    unsigned next() { state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32); return (unsigned)state; }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+// ---- polynomials in (x,y,z), total degree <= 3 ------------------------------------------------------------
+// index of monomial x^i y^j z^k
+inline int midx(int i, int j, int k) { return (i * 4 + j) * 4 + k; }
+struct Poly { double c[64]; Poly() { for (double& v : c) v = 0; } };
+inline Poly pmul(const Poly& a, const Poly& b) {
+    Poly r;
+    for (int i1 = 0; i1 < 4; i1++) for (int j1 = 0; j1 + i1 < 4; j1++) for (int k1 = 0; k1 + j1 + i1 < 4; k1++) {
+        const double av = a.c[midx(i1, j1, k1)];
+        if (av == 0.0) continue;
+        for (int i2 = 0; i2 + i1 < 4; i2++) for (int j2 = 0; j2 + j1 < 4; j2++) for (int k2 = 0; k2 + k1 < 4; k2++) {
+            if (i1 + j1 + k1 + i2 + j2 + k2 > 3) continue;
+            const double bv = b.c[midx(i2, j2, k2)];
+            if (bv == 0.0) continue;
+            r.c[midx(i1 + i2, j1 + j2, k1 + k2)] += av * bv;
+        }
+    }
+    return r;
+}
+inline Poly padd(const Poly& a, const Poly& b, double sb = 1.0) {
+    Poly r;
+    for (int i = 0; i < 64; i++) r.c[i] = a.c[i] + sb * b.c[i];
+    return r;
+}
+
+// Nistér's column order: x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1
+const int MONO[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
+                         {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+
+// cv::solvePoly (Durand–Kerner), coeffs ascending, degree n; returns roots (re, im)
+void solve_poly(const double* coeffs_in, int n0, std::vector<std::pair<double, double>>& roots_out) {
+    struct Cx { double re, im; };
+    auto mul = [](Cx a, Cx b) { return Cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; };
+    auto div = [](Cx a, Cx b) { const double t = 1. / (b.re * b.re + b.im * b.im); return Cx{(a.re * b.re + a.im * b.im) * t, (-a.re * b.im + a.im * b.re) * t}; };
+    int n = n0;
+    std::vector<Cx> coeffs(n0 + 1), roots(n0 + 1);
+    for (int i = 0; i <= n0; i++) coeffs[i] = Cx{coeffs_in[i], 0};
+    for (; n > 1; n--) if (std::abs(coeffs[n].re) + std::abs(coeffs[n].im) > DBL_EPSILON) break;
+    Cx p{1, 0}, r{1, 1};
+    for (int i = 0; i < n; i++) { roots[i] = p; p = mul(p, r); }
+    const int maxIters = 300;
+    for (int iter = 0; iter < maxIters; iter++) {
+        double maxDiff = 0;
+        for (int i = 0; i < n; i++) {
+            p = roots[i];
+            Cx num = coeffs[n], denom = coeffs[n];
+            for (int j = 0; j < n; j++) {
+                num = mul(num, p);
+                num.re += coeffs[n - j - 1].re; num.im += coeffs[n - j - 1].im;
+                if (j != i) {
+                    const Cx d{p.re - roots[j].re, p.im - roots[j].im};
+                    if (d.re != 0 || d.im != 0) denom = mul(denom, d);
+                }
+            }
+            num = div(num, denom);
+            roots[i] = Cx{p.re - num.re, p.im - num.im};
+            maxDiff = std::max(maxDiff, std::sqrt(num.re * num.re + num.im * num.im));
+        }
+        if (maxDiff <= 0) break;
+    }
+    roots_out.clear();
+    for (int i = 0; i < n; i++) {
+        if (std::fabs(roots[i].im) < 1e-100) roots[i].im = 0;
+        roots_out.push_back({roots[i].re, roots[i].im});
+    }
+}
+
+// EMEstimatorCallback::runKernel: five normalised correspondences -> up to 10 essential matrices (row-major 3x3 each)
+int five_point_kernel(const double* q1, const double* q2, double* E_out) {
+    double QtQ[81];
+    double Q[5][9];
+    for (int i = 0; i < 5; i++) {
+        const double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
+        Q[i][0] = x1 * x2; Q[i][1] = y1 * x2; Q[i][2] = x2; Q[i][3] = x1 * y2; Q[i][4] = y1 * y2; Q[i][5] = y2; Q[i][6] = x1; Q[i][7] = y1; Q[i][8] = 1.0;
+    }
+    for (int a = 0; a < 9; a++)
+        for (int b = 0; b < 9; b++) {
+            double acc = 0;
+            for (int i = 0; i < 5; i++) acc += Q[i][a] * Q[i][b];
+            QtQ[a * 9 + b] = acc;
+        }
+    double w[9], V[81];
+    vmath::jacobi_eig(QtQ, 9, w, V);
+    // EE columns 0..3 <- right singular vectors 5..8 (descending order) = eigenvectors 3,2,1,0 (ascending order)
+    double EE[4][9];
+    for (int c = 0; c < 4; c++)
+        for (int k = 0; k < 9; k++) EE[c][k] = V[k * 9 + (3 - c)];
+    // E(x,y,z) = x EE0 + y EE1 + z EE2 + EE3 as 9 linear polynomials
+    Poly Ep[9];
+    for (int k = 0; k < 9; k++) {
+        Ep[k].c[midx(1, 0, 0)] = EE[0][k]; Ep[k].c[midx(0, 1, 0)] = EE[1][k]; Ep[k].c[midx(0, 0, 1)] = EE[2][k]; Ep[k].c[midx(0, 0, 0)] = EE[3][k];
+    }
+    auto P = [&](int r, int c) -> const Poly& { return Ep[r * 3 + c]; };
+    std::vector<Poly> eqs;
+    // det(E) = 0
+    {
+        Poly d = pmul(P(0, 0), padd(pmul(P(1, 1), P(2, 2)), pmul(P(1, 2), P(2, 1)), -1.0));
+        d = padd(d, pmul(P(0, 1), padd(pmul(P(1, 0), P(2, 2)), pmul(P(1, 2), P(2, 0)), -1.0)), -1.0);
+        d = padd(d, pmul(P(0, 2), padd(pmul(P(1, 0), P(2, 1)), pmul(P(1, 1), P(2, 0)), -1.0)));
+        eqs.push_back(d);
+    }
+    // 2 E E^T E - trace(E E^T) E = 0
+    {
+        Poly EEt[9], tr;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                Poly s;
+                for (int k = 0; k < 3; k++) s = padd(s, pmul(P(i, k), P(j, k)));
+                EEt[i * 3 + j] = s;
+            }
+        tr = padd(padd(EEt[0], EEt[4]), EEt[8]);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                Poly s;
+                for (int k = 0; k < 3; k++) s = padd(s, pmul(EEt[i * 3 + k], P(k, j)));
+                Poly e = padd(s, s);                       // 2 (E E^T E)_ij
+                e = padd(e, pmul(tr, P(i, j)), -1.0);
+                eqs.push_back(e);
+            }
+    }
+    double A[10][20];
+    for (int r = 0; r < 10; r++)
+        for (int c = 0; c < 20; c++) A[r][c] = eqs[r].c[midx(MONO[c][0], MONO[c][1], MONO[c][2])];
+    // A <- A[:, :10]^-1 A[:, 10:]  (Gauss–Jordan with partial pivoting)
+    for (int c = 0; c < 10; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 10; r++) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+        if (std::fabs(A[piv][c]) < 1e-300) return 0;
+        if (piv != c) for (int k = 0; k < 20; k++) std::swap(A[c][k], A[piv][k]);
+        const double inv = 1.0 / A[c][c];
+        for (int k = 0; k < 20; k++) A[c][k] *= inv;
+        for (int r = 0; r < 10; r++) {
+            if (r == c) continue;
+            const double f = A[r][c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < 20; k++) A[r][k] -= f * A[c][k];
+        }
+    }
+    // B(z) [x y 1]^T = 0 with rows (x^2z-row) - z (x^2-row), (y^2z) - z (y^2), (xyz) - z (xy)
+    double b[3 * 13];
+    for (int i = 0; i < 3; i++) {
+        const double* a1 = &A[i * 2 + 4][10];
+        const double* a2 = &A[i * 2 + 5][10];
+        double row1[13] = {0}, row2[13] = {0};
+        for (int k = 0; k < 3; k++) { row1[1 + k] = a1[k]; row1[5 + k] = a1[3 + k]; row2[k] = a2[k]; row2[4 + k] = a2[3 + k]; }
+        for (int k = 0; k < 4; k++) { row1[9 + k] = a1[6 + k]; row2[8 + k] = a2[6 + k]; }
+        for (int k = 0; k < 13; k++) b[i * 13 + k] = row1[k] - row2[k];
+    }
+    // det B(z): polynomial of degree 10 (coefficients ascending)
+    auto polyz = [&](int row, int col, double* out) -> int {   // ascending coefficients; returns degree
+        const double* br = b + row * 13;
+        if (col == 0) { out[0] = br[3]; out[1] = br[2]; out[2] = br[1]; out[3] = br[0]; return 3; }
+        if (col == 1) { out[0] = br[7]; out[1] = br[6]; out[2] = br[5]; out[3] = br[4]; return 3; }
+        out[0] = br[12]; out[1] = br[11]; out[2] = br[10]; out[3] = br[9]; out[4] = br[8];
+        return 4;
+    };
+    double c[11];
+    for (double& v : c) v = 0;
+    const int perms[6][4] = {{0, 1, 2, 1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {2, 1, 0, -1}, {1, 0, 2, -1}, {0, 2, 1, -1}};
+    for (auto& pm : perms) {
+        double p0[5], p1[5], p2[5];
+        const int d0 = polyz(0, pm[0], p0), d1 = polyz(1, pm[1], p1), d2 = polyz(2, pm[2], p2);
+        double t01[9] = {0};
+        for (int i = 0; i <= d0; i++) for (int j = 0; j <= d1; j++) t01[i + j] += p0[i] * p1[j];
+        for (int i = 0; i <= d0 + d1; i++) for (int j = 0; j <= d2; j++) c[i + j] += pm[3] * t01[i] * p2[j];
+    }
+    std::vector<std::pair<double, double>> roots;
+    solve_poly(c, 10, roots);
+    int count = 0;
+    for (auto& rt : roots) {
+        if (std::fabs(rt.second) > 1e-10) continue;
+        const double z1 = rt.first, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        double bz[9];
+        for (int j = 0; j < 3; j++) {
+            const double* br = b + j * 13;
+            bz[j * 3 + 0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
+            bz[j * 3 + 1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
+            bz[j * 3 + 2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+        }
+        // SVD::solveZ: unit null vector = eigenvector of the smallest eigenvalue of Bz^T Bz
+        double BtB[9], ew[3], eV[9];
+        for (int a = 0; a < 3; a++)
+            for (int bb = 0; bb < 3; bb++) BtB[a * 3 + bb] = bz[a] * bz[bb] + bz[3 + a] * bz[3 + bb] + bz[6 + a] * bz[6 + bb];
+        vmath::jacobi_eig(BtB, 3, ew, eV);
+        const double xy1[3] = {eV[0], eV[3], eV[6]};
+        if (std::fabs(xy1[2]) < 1e-10) continue;
+        const double xs = xy1[0] / xy1[2], ys = xy1[1] / xy1[2];
+        double Ev[9], nrm = 0;
+        for (int k = 0; k < 9; k++) { Ev[k] = EE[0][k] * xs + EE[1][k] * ys + EE[2][k] * z1 + EE[3][k]; nrm += Ev[k] * Ev[k]; }
+        nrm = std::sqrt(nrm);
+        for (int k = 0; k < 9; k++) E_out[count * 9 + k] = Ev[k] / nrm;
+        count++;
+        if (count == 10) break;
+    }
+    return count;
+}
+
+// EMEstimatorCallback::computeError (Sampson distance, stored as float32)
+void sampson_errors(const double* E, const double* q1, const double* q2, int n, float* err) {
+    for (int i = 0; i < n; i++) {
+        const double x1[3] = {q1[2 * i], q1[2 * i + 1], 1.}, x2[3] = {q2[2 * i], q2[2 * i + 1], 1.};
+        const double Ex1[3] = {E[0] * x1[0] + E[1] * x1[1] + E[2] * x1[2], E[3] * x1[0] + E[4] * x1[1] + E[5] * x1[2], E[6] * x1[0] + E[7] * x1[1] + E[8] * x1[2]};
+        const double Etx2[3] = {E[0] * x2[0] + E[3] * x2[1] + E[6] * x2[2], E[1] * x2[0] + E[4] * x2[1] + E[7] * x2[2], E[2] * x2[0] + E[5] * x2[1] + E[8] * x2[2]};
+        const double x2tEx1 = x2[0] * Ex1[0] + x2[1] * Ex1[1] + x2[2] * Ex1[2];
+        const double a = Ex1[0] * Ex1[0], b = Ex1[1] * Ex1[1], c = Etx2[0] * Etx2[0], d = Etx2[1] * Etx2[1];
+        err[i] = (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+    }
+}
+
+int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = std::max(p, 0.); p = std::min(p, 1.);
+    ep = std::max(ep, 0.); ep = std::min(ep, 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)lrint(num / denom);
+}
+
+}  // namespace
+
+// cv::findEssentialMat(points1, points2, K, RANSAC, prob, threshold, mask): returns false when no model was found
+bool find_essential_mat(const double* p1, const double* p2, int n, const double* K, double prob, double threshold,
+                        double* E, std::vector<uint8_t>& mask) {
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    std::vector<double> q1(2 * n), q2(2 * n);
+    for (int i = 0; i < n; i++) {
+        q1[2 * i] = (p1[2 * i] - cx) / fx; q1[2 * i + 1] = (p1[2 * i + 1] - cy) / fy;
+        q2[2 * i] = (p2[2 * i] - cx) / fx; q2[2 * i + 1] = (p2[2 * i + 1] - cy) / fy;
+    }
+    threshold /= (fx + fy) / 2;
+    const int modelPoints = 5;
+    mask.assign(n, 0);
+    if (n < modelPoints) return false;
+    std::vector<float> err(n);
+    std::vector<uint8_t> cur(n);
+    double models[90], best[9];
+    int maxGood = 0, niters = 1000;
+    const float thr = (float)(threshold * threshold);
+    RNG rng((uint64_t)-1);
+    auto evaluate = [&](int nmodels) {
+        for (int mi = 0; mi < nmodels; mi++) {
+            sampson_errors(models + 9 * mi, q1.data(), q2.data(), n, err.data());
+            int good = 0;
+            for (int i = 0; i < n; i++) { const int f = err[i] <= thr; cur[i] = (uint8_t)f; good += f; }
+            if (good > std::max(maxGood, modelPoints - 1)) {
+                std::swap(cur, mask);
+                memcpy(best, models + 9 * mi, sizeof(best));
+                maxGood = good;
+                niters = ransac_update_num_iters(prob, (double)(n - good) / n, modelPoints, niters);
+            }
+        }
+    };
+    if (n == modelPoints) {
+        const int nm = five_point_kernel(q1.data(), q2.data(), models);
+        if (nm <= 0) return false;
+        memcpy(E, models, 9 * sizeof(double));
+        mask.assign(n, 1);
+        return true;
+    }
+    for (int iter = 0; iter < niters; iter++) {
+        int idx[5];
+        for (int i = 0; i < modelPoints;) {
+            int idx_i;
+            for (;;) {
+                idx_i = idx[i] = rng.uniform(0, n);
+                int j = 0;
+                for (; j < i; j++) if (idx_i == idx[j]) break;
+                if (j == i) break;
+            }
+            i++;
+        }
+        double s1[10], s2[10];
+        for (int i = 0; i < 5; i++) { s1[2 * i] = q1[2 * idx[i]]; s1[2 * i + 1] = q1[2 * idx[i] + 1]; s2[2 * i] = q2[2 * idx[i]]; s2[2 * i + 1] = q2[2 * idx[i] + 1]; }
+        const int nm = five_point_kernel(s1, s2, models);
+        if (nm <= 0) continue;
+        evaluate(nm);
+    }
+    if (maxGood <= 0) { mask.assign(n, 0); return false; }
+    memcpy(E, best, sizeof(best));
+    return true;
+}
+
+// cv::recoverPose(E, points1, points2, K, R, t, distanceThresh = HUGE_VAL, mask (in/out), triangulatedPoints 4xN)
+int recover_pose(const double* E, const double* p1, const double* p2, int n, const double* K, double* R_out, double* t_out,
+                 std::vector<uint8_t>& mask, std::vector<double>& tri4) {
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    std::vector<double> q1(2 * n), q2(2 * n);
+    for (int i = 0; i < n; i++) {
+        q1[2 * i] = (p1[2 * i] - cx) / fx; q1[2 * i + 1] = (p1[2 * i + 1] - cy) / fy;
+        q2[2 * i] = (p2[2 * i] - cx) / fx; q2[2 * i + 1] = (p2[2 * i + 1] - cy) / fy;
+    }
+    // decomposeEssentialMat
+    double U[9], s[3], V[9], Vt[9];
+    vmath::svd3(E, U, s, V);
+    vmath::mat3_T(V, Vt);
+    if (vmath::det3(U) < 0) for (double& v : U) v = -v;
+    if (vmath::det3(Vt) < 0) for (double& v : Vt) v = -v;
+    const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+    double R1[9], R2[9], tmp[9];
+    vmath::mat3_mul(U, W, tmp); vmath::mat3_mul(tmp, Vt, R1);
+    vmath::mat3_mul(U, Wt, tmp); vmath::mat3_mul(tmp, Vt, R2);
+    const double tv[3] = {U[2], U[5], U[8]};
+    const double* Rs[4] = {R1, R2, R1, R2};
+    const double tsgn[4] = {1, 1, -1, -1};
+    std::vector<std::vector<uint8_t>> masks(4, std::vector<uint8_t>(n, 0));
+    std::vector<std::vector<double>> tris(4, std::vector<double>((size_t)4 * n));
+    int good[4] = {0, 0, 0, 0};
+    for (int c = 0; c < 4; c++) {
+        double P1[12];
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) P1[i * 4 + j] = Rs[c][i * 3 + j]; P1[i * 4 + 3] = tsgn[c] * tv[i]; }
+        const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        for (int i = 0; i < n; i++) {
+            // cvTriangulatePoints: 4x4 DLT, solution = right singular vector of the smallest singular value
+            double A[16];
+            const double* Ps[2] = {P0, P1};
+            const double xs[2] = {q1[2 * i], q2[2 * i]}, ys[2] = {q1[2 * i + 1], q2[2 * i + 1]};
+            for (int j = 0; j < 2; j++)
+                for (int k = 0; k < 4; k++) {
+                    A[(j * 2) * 4 + k] = xs[j] * Ps[j][8 + k] - Ps[j][k];
+                    A[(j * 2 + 1) * 4 + k] = ys[j] * Ps[j][8 + k] - Ps[j][4 + k];
+                }
+            double AtA[16], w4[4], V4[16];
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++) {
+                    double acc = 0;
+                    for (int k = 0; k < 4; k++) acc += A[k * 4 + a] * A[k * 4 + b];
+                    AtA[a * 4 + b] = acc;
+                }
+            vmath::jacobi_eig(AtA, 4, w4, V4);
+            double Qh[4] = {V4[0], V4[4], V4[8], V4[12]};
+            for (int k = 0; k < 4; k++) tris[c][(size_t)k * n + i] = Qh[k];
+            bool m = Qh[2] * Qh[3] > 0;
+            const double Qn[4] = {Qh[0] / Qh[3], Qh[1] / Qh[3], Qh[2] / Qh[3], Qh[3] / Qh[3]};
+            m = m && (Qn[2] < HUGE_VAL);
+            const double z2 = P1[8] * Qn[0] + P1[9] * Qn[1] + P1[10] * Qn[2] + P1[11] * Qn[3];
+            m = m && (z2 > 0) && (z2 < HUGE_VAL);
+            m = m && mask[i];
+            masks[c][i] = m ? 1 : 0;
+            good[c] += m ? 1 : 0;
+        }
+    }
+    int sel;
+    if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) sel = 0;
+    else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) sel = 1;
+    else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) sel = 2;
+    else sel = 3;
+    memcpy(R_out, Rs[sel], 9 * sizeof(double));
+    for (int i = 0; i < 3; i++) t_out[i] = tsgn[sel] * tv[i];
+    mask = masks[sel];
+    tri4 = tris[sel];
+    return good[sel];
+}
+
+// ---- OpenCVFivePointTri.cpp:5-54 ---------------------------------------------------------------------------------
+void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
+    const int j = src.frame;
+    std::vector<double> p1, p2;
+    std::vector<std::shared_ptr<Feature>> p1_ptr, p2_ptr;
+    for (auto& p : src.feat_corr) {
+        if (p.first.expired() || p.second.expired()) continue;
+        std::shared_ptr<Feature> fst = p.first.lock();
+        std::shared_ptr<Feature> sec = p.second.lock();
+        p1.push_back(fst->column); p1.push_back(fst->row);     // integer cv::Point (quirk Q12)
+        p2.push_back(sec->column); p2.push_back(sec->row);
+        p1_ptr.push_back(fst);
+        p2_ptr.push_back(sec);
+    }
+    const int n = (int)p1_ptr.size();
+    std::vector<uint8_t> mask;
+    std::vector<double> tri;
+    double E[9];
+    const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask);
+    if (!ok) {
+        // cv::recoverPose on an empty E raises in the reference (uncaught). Keep the pipeline alive: no motion, no landmarks.
+        R_out = Mat3::eye();
+        t_out = Vec3{{0, 0, 0}};
+        return;
+    }
+    recover_pose(E, p1.data(), p2.data(), n, tracker->camera, R_out.m, t_out.v, mask, tri);
+    const Vec3& g1 = tracker->gt_t[j + tracker->init_offset + 1];
+    const Vec3& g0 = tracker->gt_t[j + tracker->init_offset];
+    const double d0 = g1.v[0] - g0.v[0], d1 = g1.v[1] - g0.v[1], d2 = g1.v[2] - g0.v[2];
+    tracker->scale = std::sqrt(std::pow(d0, 2) + std::pow(d1, 2) + std::pow(d2, 2));
+    t_out = tracker->scale * t_out;
+    for (int i = 0; i < n; i++) {
+        if (!mask[i]) continue;   // Removing RANSAC outliers
+        const double w = tri[(size_t)3 * n + i];
+        std::shared_ptr<Feature3D> f3d = std::make_shared<Feature3D>(tracker->scale * tri[i] / w, tracker->scale * tri[(size_t)n + i] / w,
+                                                                      tracker->scale * tri[(size_t)2 * n + i] / w * -1);
+        if (f3d->z < 0) {
+            f3d->id = tracker->next_landmark_id++;
+            f3d->transform(tracker->R[j], tracker->t[j]);
+            tracker->feats3d.push_back(f3d);
+            next.map[p2_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
+            src.map[p1_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
+        }
+    }
+}
+
+}  // namespace vo

@@ -1,0 +1,412 @@
+// See vo_pipeline.h. Line references are into /root/reference/.
+#include "vo_pipeline.h"
+#include "vo_math.h"
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <cfloat>
+
+namespace vo {
+
+// ---- Feature::Hasher support: hash<string>(to_string(v)) memoised ------------------------------------------
+size_t coord_hash(int v) {
+    static const int LO = -4096, HI = 16384;
+    static std::vector<size_t>* table = [] {
+        auto* t = new std::vector<size_t>(HI - LO);
+        for (int i = LO; i < HI; i++) (*t)[i - LO] = std::hash<std::string>{}(std::to_string(i));
+        return t;
+    }();
+    if (v >= LO && v < HI) return (*table)[v - LO];
+    return std::hash<std::string>{}(std::to_string(v));
+}
+
+void rodrigues_v2m(const double r[3], double R[9]) { vmath::rodrigues_v2m(r, R); }
+void rodrigues_m2v(const double R[9], double r[3]) { vmath::rodrigues_m2v(R, r); }
+
+// ---- OpenCVGoodFeatureExtractor.cpp:4-21 -------------------------------------------------------------------
+static std::vector<Feature> corners_to_features(const std::vector<std::pair<int, int>>& c, const std::vector<double>* score,
+                                                Feature::extractor det) {
+    std::vector<Feature> feats;
+    for (size_t i = 0; i < c.size(); i++) {
+        Feature f;                 // default ctor: tracked = false
+        f.row = c[i].second;
+        f.column = c[i].first;
+        f.detector = det;
+        if (det == Feature::cv_good) f.tracked = true;   // :16 (ShiTomasi leaves tracked=false, its score is set instead)
+        if (score) f.score = (*score)[i];
+        feats.push_back(f);
+    }
+    return feats;
+}
+std::vector<Feature> GoodFeatureExtractorBase::extractFeatures(Frame& src, int max) {
+    std::vector<ImageView> cells{src.bw};
+    std::vector<std::vector<std::pair<int, int>>> out;
+    gftt(cells, max, out);
+    return corners_to_features(out[0], nullptr, Feature::cv_good);
+}
+std::vector<std::vector<Feature>> GoodFeatureExtractorBase::extractGrid(std::vector<Frame>& cells, int max) {
+    std::vector<ImageView> views;
+    for (auto& c : cells) views.push_back(c.bw);
+    std::vector<std::vector<std::pair<int, int>>> out;
+    gftt(views, max, out);
+    std::vector<std::vector<Feature>> res;
+    for (auto& o : out) res.push_back(corners_to_features(o, nullptr, Feature::cv_good));
+    return res;
+}
+// ---- ShiTomasiFeatureExtractor.cpp:5-47 --------------------------------------------------------------------
+std::vector<Feature> ShiTomasiExtractorBase::extractFeatures(Frame& src, int max) {
+    std::vector<ImageView> cells{src.bw};
+    std::vector<std::vector<std::pair<int, int>>> out;
+    std::vector<std::vector<double>> sc;
+    shitomasi(cells, max, out, sc);
+    return corners_to_features(out[0], &sc[0], Feature::shi_tomasi);
+}
+std::vector<std::vector<Feature>> ShiTomasiExtractorBase::extractGrid(std::vector<Frame>& cells, int max) {
+    std::vector<ImageView> views;
+    for (auto& c : cells) views.push_back(c.bw);
+    std::vector<std::vector<std::pair<int, int>>> out;
+    std::vector<std::vector<double>> sc;
+    shitomasi(views, max, out, sc);
+    std::vector<std::vector<Feature>> res;
+    for (size_t i = 0; i < out.size(); i++) res.push_back(corners_to_features(out[i], &sc[i], Feature::shi_tomasi));
+    return res;
+}
+
+// ---- OpenCVLucasKanadeFM.cpp:5-32 ----------------------------------------------------------------------------
+fmap LucasKanadeFMBase::matchFeatures(Frame& src, Frame& next) {
+    fmap correspondences;
+    std::vector<float> prev_points, next_points;
+    for (auto const& p : src.map) {
+        prev_points.push_back((float)p.first->column);
+        prev_points.push_back((float)p.first->row);
+    }
+    const int n = (int)(prev_points.size() / 2);
+    next_points.resize(prev_points.size());
+    std::vector<uint8_t> status(n);
+    std::vector<float> err(n);
+    if (n > 0) pyrlk(src.bw, next.bw, prev_points.data(), n, next_points.data(), status.data(), err.data());
+    int i = 0;
+    for (auto const& p : src.map) {
+        if ((int)status.size() < i + 1) continue;
+        if (status[i]) {
+            // Feature(next_points[i].x, next_points[i].y): float -> int truncation toward zero
+            std::shared_ptr<Feature> f = std::make_shared<Feature>(Feature((int)next_points[2 * i], (int)next_points[2 * i + 1]));
+            next.map[f] = p.second;
+            correspondences[p.first] = f;
+        }
+        i++;
+    }
+    return correspondences;
+}
+
+// ---- OpenCVEPnPSolver.cpp:4-50 ---------------------------------------------------------------------------------
+void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
+    const int j = src.frame;
+    std::vector<float> obj_points, img_points;
+    double _R_rod[3];
+    rodrigues_m2v(R_out.m, _R_rod);
+    std::vector<std::weak_ptr<Feature3D>> local_feats3d;
+    for (auto& p : src.map) {
+        if (p.second.expired()) continue;
+        std::shared_ptr<Feature3D> f3d = p.second.lock();
+        if (src.feat_corr[p.first].expired()) continue;      // operator[] inserts empty entries (quirk Q10)
+        std::shared_ptr<Feature> f = src.feat_corr[p.first].lock();
+        next.map[f] = std::weak_ptr<Feature3D>(f3d);
+        f3d->transformInv(tracker->R[j], tracker->t[j]);
+        float px = f3d->x, py = f3d->y, pz = f3d->z;
+        pz *= -1;
+        obj_points.push_back(px); obj_points.push_back(py); obj_points.push_back(pz);
+        img_points.push_back((float)f->column); img_points.push_back((float)f->row);
+        f3d->transform(tracker->R[j], tracker->t[j]);       // float round trip (quirk Q7)
+        local_feats3d.push_back(f3d);
+    }
+    std::vector<int> inliers;
+    const int m = (int)(obj_points.size() / 3);
+    tracker->stats.pnp_calls++; tracker->stats.pnp_points += m;
+    pnp_ransac(obj_points.data(), img_points.data(), m, tracker->camera, _R_rod, t_out.v, inliers);
+    rodrigues_v2m(_R_rod, R_out.m);
+    // Removing RANSAC outliers (:40-49)
+    std::vector<uint8_t> is_inlier(m, 0);
+    for (int i : inliers) if (i >= 0 && i < m) is_inlier[i] = 1;
+    for (int i = 0; i < m; i++) {
+        if (!is_inlier[i]) {
+            if (local_feats3d[i].expired()) continue;
+            std::shared_ptr<Feature3D> f3d = local_feats3d[i].lock();
+            auto it = std::find(tracker->feats3d.begin(), tracker->feats3d.end(), f3d);
+            tracker->feats3d.erase(it);
+        }
+    }
+}
+
+// ---- CeresBundleAdjustment.cpp:5-89 ------------------------------------------------------------------------------
+void BundleAdjustmentBase::apply(Frame& f) {
+    const int fn = (int)f.frame + 1;
+    const int n = std::min(tracker->cfg.bundle_size, fn);
+    std::vector<int> cam_frame;                 // window frames in order (skipping 0)
+    std::vector<double> tr_opt;                 // 6 per window frame
+    std::vector<double> obs;                    // 2 per residual block
+    std::vector<int> obs_cam, obs_pt;
+    std::unordered_map<std::shared_ptr<Feature3D>, int> p3d_index;
+    std::vector<std::shared_ptr<Feature3D>> p3d_ptr;
+    std::vector<double> p3d_opt;
+    for (int i = fn - n; i < fn; i++) {
+        if (i == 0) continue;
+        std::shared_ptr<Frame> frame = tracker->frames[i];
+        double rod[3];
+        Mat3 Rt = tracker->R[i].t();
+        rodrigues_m2v(Rt.m, rod);
+        const int ci = (int)cam_frame.size();
+        cam_frame.push_back(i);
+        tr_opt.push_back(rod[0]); tr_opt.push_back(rod[1]); tr_opt.push_back(rod[2]);
+        tr_opt.push_back(-tracker->t[i].v[0]); tr_opt.push_back(-tracker->t[i].v[1]); tr_opt.push_back(-tracker->t[i].v[2]);
+        for (auto& p : frame->map) {
+            if (p.second.expired()) continue;
+            std::shared_ptr<Feature3D> f3d = p.second.lock();
+            std::shared_ptr<Feature> ft = p.first;
+            obs.push_back((double)ft->column); obs.push_back((double)ft->row);
+            auto it = p3d_index.find(f3d);
+            int pi;
+            if (it == p3d_index.end()) {
+                pi = (int)p3d_ptr.size();
+                p3d_index[f3d] = pi;
+                p3d_ptr.push_back(f3d);
+                p3d_opt.push_back(f3d->x); p3d_opt.push_back(f3d->y); p3d_opt.push_back(f3d->z);
+            } else pi = it->second;
+            obs_cam.push_back(ci); obs_pt.push_back(pi);
+        }
+    }
+    const int n_obs = (int)obs_cam.size();
+    // Only parameter blocks that appear in a residual block are part of the Ceres problem: compact the cameras.
+    std::vector<int> remap(cam_frame.size(), -1);
+    std::vector<double> cams_c;
+    int nc = 0;
+    {
+        std::vector<uint8_t> used(cam_frame.size(), 0);
+        for (int c : obs_cam) used[c] = 1;
+        for (size_t c = 0; c < cam_frame.size(); c++)
+            if (used[c]) { remap[c] = nc++; for (int k = 0; k < 6; k++) cams_c.push_back(tr_opt[c * 6 + k]); }
+        for (int& c : obs_cam) c = remap[c];
+    }
+    tracker->stats.ba_calls++; tracker->stats.ba_obs += n_obs; tracker->stats.ba_points += (long)p3d_ptr.size();
+    if (n_obs > 0)
+        ba_solve(cams_c.data(), nc, p3d_opt.data(), (int)p3d_ptr.size(), obs.data(), obs_cam.data(), obs_pt.data(), n_obs,
+                 tracker->camera, 1.0, tracker->cfg.ba_iterations);
+    for (size_t c = 0; c < cam_frame.size(); c++)
+        if (remap[c] >= 0) for (int k = 0; k < 6; k++) tr_opt[c * 6 + k] = cams_c[remap[c] * 6 + k];
+    // Updating 3D points and camera poses (:67-88)
+    for (size_t c = 0; c < cam_frame.size(); c++) {
+        const int i = cam_frame[c];
+        const double rod[3] = {tr_opt[c * 6], tr_opt[c * 6 + 1], tr_opt[c * 6 + 2]};
+        Mat3 _R;
+        rodrigues_v2m(rod, _R.m);
+        tracker->R[i] = _R.t();
+        tracker->t[i] = Vec3{{-tr_opt[c * 6 + 3], -tr_opt[c * 6 + 4], -tr_opt[c * 6 + 5]}};
+        for (size_t p = 0; p < p3d_ptr.size(); p++) p3d_ptr[p]->update(p3d_opt[p * 3], p3d_opt[p * 3 + 1], p3d_opt[p * 3 + 2]);
+    }
+}
+
+// ---- OdometryPipeline ------------------------------------------------------------------------------------------------
+double OdometryPipeline::standardDeviation(const std::vector<double>& val) {   // :660-672
+    double avg = 0, sd = 0;
+    for (auto const& v : val) avg += v;
+    avg /= val.size();
+    for (auto const& v : val) sd += std::pow(v - avg, 2);
+    return std::sqrt(sd / (val.size() - 1));
+}
+
+double OdometryPipeline::calcYRotation(const Mat3& R, bool flip) {   // OdometryPipeline.h:89-108
+    const double c = R(0, 0), s = R(0, 2);
+    if (flip) return s <= 0 ? -std::acos(c) : std::acos(c);
+    return s <= 0 ? std::acos(c) : -std::acos(c);
+}
+
+std::vector<OdometryPipeline::GridSection> OdometryPipeline::getGridROI(Frame& fr) {   // :674-693
+    std::vector<GridSection> roi;
+    const int rows = fr.bw.h, cols = fr.bw.w;
+    for (int r = 0; r < rows; r += cfg.grid_size[0])
+        for (int c = 0; c < cols; c += cfg.grid_size[1]) {
+            const int rw = std::min(cfg.grid_size[1], cols - c), rh = std::min(cfg.grid_size[0], rows - r);
+            roi.push_back(GridSection{c / cfg.grid_size[1], r / cfg.grid_size[0], fr.regionOfInterest(c, r, rw, rh)});
+        }
+    return roi;
+}
+
+void OdometryPipeline::initialise() {   // :428-482
+    int i = 0;
+    Frame best = *(frames[0]);
+    double cost = HUGE_VAL;
+    for (auto& fr : frames) {
+        std::vector<GridSection> roi = getGridROI(*fr);
+        double n = cfg.min_tracked_features / roi.size();   // integer division (quirk Q6)
+        std::vector<double> n_i, s_i;
+        std::vector<Frame> cells;
+        for (auto& r : roi) cells.push_back(r.frame);
+        std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, (int)n);
+        stats.detect_calls++;
+        for (size_t k = 0; k < roi.size(); k++) {
+            std::vector<Feature>& feats = all[k];
+            n_i.push_back((double)feats.size());
+            for (auto& f : feats) {
+                f.column = roi[k].x * cfg.grid_size[1] + f.column;
+                f.row = roi[k].y * cfg.grid_size[0] + f.row;
+                s_i.push_back(f.score);
+                fr->map[std::make_shared<Feature>(f)] = std::weak_ptr<Feature3D>();
+            }
+        }
+        const double std_n = standardDeviation(n_i), std_s = standardDeviation(s_i);
+        const double _cost = std_n + std_s;
+        if (_cost < cost) {
+            fr->frame = 0;
+            best = *fr;
+            cost = _cost;
+            init_offset = i;
+        }
+        i++;
+    }
+    frames.clear();
+    frames.push_back(std::make_shared<Frame>(best));
+}
+
+void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
+    frame.frame = (int)frames.size();
+    fmap feat_corr = matcher->matchFeatures(*(frames[frame.frame - 1]), frame);
+    stats.lk_calls++; stats.lk_points += (long)frames[frame.frame - 1]->map.size();
+    frames[frame.frame - 1]->feat_corr = feat_corr;
+    if ((int)feat_corr.size() < cfg.tracked_features_tol) {
+        std::vector<GridSection> roi = getGridROI(*(frames[frames.size() - 1]));   // cells of the PREVIOUS frame (quirk Q3)
+        const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
+        std::vector<Frame> cells;
+        for (auto& r : roi) cells.push_back(r.frame);
+        std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
+        stats.detect_calls++;
+        for (size_t k = 0; k < roi.size(); k++)
+            for (auto& f : all[k]) {
+                if (!frame.hasNeighbor(f)) {   // cell-LOCAL coordinates vs the global map (quirk Q4)
+                    f.column = roi[k].x * cfg.grid_size[1] + f.column;
+                    f.row = roi[k].y * cfg.grid_size[0] + f.row;
+                    frame.map[std::make_shared<Feature>(f)] = std::weak_ptr<Feature3D>();
+                }
+            }
+    }
+    frames.push_back(std::make_shared<Frame>(frame));
+}
+
+void OdometryPipeline::motionHeuristics(Mat3& _R, Vec3& _t, int j) {   // :171-208
+    if (_t(2) < 0 && calcYRotation(_R) < 3.1415 / 8 &&
+        std::abs(_t(2)) > std::max(std::abs(_t(0)), std::abs(_t(1))) && std::abs(_t(2)) < 2 * scale) {
+        t_s.push_back(_t);
+        R_s.push_back(_R);
+        _t = R[j] * _t + t[j];
+        _R = _R * R[j];
+    } else {
+        stats.heuristic_motion++;
+        t_s.push_back(t_s[j]);
+        R_s.push_back(R_s[j]);
+        _t = R[j] * t_s[j] + t[j];
+        _R = R_s[j] * R[j];
+    }
+    t.push_back(_t);
+    R.push_back(_R);
+}
+
+void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
+    const int j = src.frame;
+    Mat3 _R = R[j];
+    Vec3 _t = t[j];
+    if (src.count3DPoints() >= cfg.tracked_features_tol) {
+        pnpsolver->solvePnP(src, next, _R, _t);
+    } else {
+        triangulator->triangulate(src, next, _R, _t);
+        stats.tri_calls++;
+    }
+    motionHeuristics(_R, _t, j);
+    // (frames[src.frame], frames[next.frame] are updated in place; the reference works on copies and writes them back)
+    if (cfg.bundle_size && src.frame && src.frame % (cfg.bundle_size / 3 * 2) == 0) ba->apply(next);
+}
+
+void OdometryPipeline::run() {   // startPipeline :247-264 + featureExtractionThread :212-229 + poseEstimationThread :237-243
+    for (int i = 0; i < cfg.init_frames; i++) frames.push_back(std::make_shared<Frame>(Frame(images[i])));
+    initialise();
+    R.push_back(Mat3::eye()); t.push_back(Vec3{{0, 0, 0}});
+    R_s.push_back(Mat3::eye()); t_s.push_back(Vec3{{0, 0, 0}});
+    for (int i = init_offset + 1; i < (int)images.size(); i++) {
+        if (i >= cfg.stop) break;
+        Frame frame(images[i]);
+        if (frame.isEmpty()) continue;
+        addFrame(frame);
+        if (on_frame_added) on_frame_added(frame.frame);
+        if (frame.frame < 2) continue;
+        const int j = frame.frame - 2;
+        estimatePose(*frames[j], *frames[j + 1]);
+    }
+}
+
+void OdometryPipeline::run_threaded() {
+    for (int i = 0; i < cfg.init_frames; i++) frames.push_back(std::make_shared<Frame>(Frame(images[i])));
+    initialise();
+    R.push_back(Mat3::eye()); t.push_back(Vec3{{0, 0, 0}});
+    R_s.push_back(Mat3::eye()); t_s.push_back(Vec3{{0, 0, 0}});
+    // job pipe (dlib::pipe<Job> in the reference). `frames` only grows at the back (front-end) while the back-end touches
+    // entries j, j+1 <= k-1 that the front-end no longer reads; the vector itself is guarded by a mutex.
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> jobs;
+    bool done = false;
+    std::vector<std::shared_ptr<Frame>> shared_frames;   // stable snapshot pointers for the back-end
+    std::thread back([&]() {
+        for (;;) {
+            int j;
+            std::shared_ptr<Frame> a, b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !jobs.empty() || done; });
+                if (jobs.empty()) return;
+                j = jobs.front(); jobs.pop_front();
+                a = frames[j]; b = frames[j + 1];
+            }
+            estimatePose(*a, *b);
+        }
+    });
+    for (int i = init_offset + 1; i < (int)images.size(); i++) {
+        if (i >= cfg.stop) break;
+        Frame frame(images[i]);
+        if (frame.isEmpty()) continue;
+        {
+            // addFrame reads frames[k-1] and appends frames[k]; BA reads tracker->frames[i] under the same lock domain
+            std::unique_lock<std::mutex> lk(mu);
+            frame.frame = (int)frames.size();
+        }
+        std::shared_ptr<Frame> prev;
+        { std::unique_lock<std::mutex> lk(mu); prev = frames[frame.frame - 1]; }
+        fmap feat_corr = matcher->matchFeatures(*prev, frame);
+        stats.lk_calls++; stats.lk_points += (long)prev->map.size();
+        prev->feat_corr = feat_corr;
+        if ((int)feat_corr.size() < cfg.tracked_features_tol) {
+            std::vector<GridSection> roi = getGridROI(*prev);
+            const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
+            std::vector<Frame> cells;
+            for (auto& r : roi) cells.push_back(r.frame);
+            std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
+            stats.detect_calls++;
+            for (size_t k = 0; k < roi.size(); k++)
+                for (auto& f : all[k])
+                    if (!frame.hasNeighbor(f)) {
+                        f.column = roi[k].x * cfg.grid_size[1] + f.column;
+                        f.row = roi[k].y * cfg.grid_size[0] + f.row;
+                        frame.map[std::make_shared<Feature>(f)] = std::weak_ptr<Feature3D>();
+                    }
+        }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            frames.push_back(std::make_shared<Frame>(frame));
+            if (frame.frame >= 2) { jobs.push_back(frame.frame - 2); cv.notify_one(); }
+        }
+        if (on_frame_added) on_frame_added(frame.frame);
+    }
+    { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_one(); }
+    back.join();
+}
+
+}  // namespace vo

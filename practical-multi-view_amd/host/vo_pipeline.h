@@ -1,0 +1,121 @@
+// Host orchestration of the VO hot path: an OpenCV/dlib-free mirror of the reference's OdometryPipeline
+// (/root/reference/OdometryPipeline.cpp: initialise :428-482, addFrame :329-374, estimatePose :376-426,
+// motionHeuristics :171-208, getGridROI :674-693, standardDeviation :660-672) plus the gather/scatter halves of its
+// plugin adapters (OpenCVLucasKanadeFM.cpp:5-32, OpenCVGoodFeatureExtractor.cpp:4-21, OpenCVEPnPSolver.cpp:4-50,
+// OpenCVFivePointTri.cpp:5-54, CeresBundleAdjustment.cpp:5-89).  The numerics those adapters hand to OpenCV/Ceres are
+// virtual "kernel" hooks: the product implements them with the HIP C ABI (include/pmv_hip.h), the oracle with its CPU
+// restatement.  GUI, drawing, video, config parsing and the error file are out of scope.
+#pragma once
+#include "vo_types.h"
+#include <functional>
+
+namespace vo {
+
+struct Config {   // the keys of the reference's config file that reach the hot path (OdometryPipeline.cpp:50-58)
+    int min_tracked_features = 400;
+    int tracked_features_tol = 150;
+    int init_frames = 5;
+    int stop = 1 << 30;       // "frames"
+    int bundle_size = 5;
+    int ba_iterations = 5;    // "max_iterations"
+    int grid_size[2] = {255, 255};   // OdometryPipeline.h:31
+    // plugin constants hard-coded in the reference
+    double gftt_quality = 0.01, gftt_min_distance = 5;   // OpenCVGoodFeatureExtractor.h:9,11
+    int extractor = 0;        // 0 = OpenCVGoodFeatureExtractor (default, OdometryPipeline.cpp:68), 1 = ShiTomasiFeatureExtractor
+    double shitomasi_quality = 0.4;                      // ShiTomasiFeatureExtractor.h:10
+};
+
+class OdometryPipeline;
+
+// ---- adapters: the reference's plugin classes with the third-party call factored into a pure-virtual hook ----
+class GoodFeatureExtractorBase : public BaseFeatureExtractor {   // OpenCVGoodFeatureExtractor
+public:
+    double quality = 0.01, min_distance = 5;
+    // cells share one full image; out[i] = corners (x,y) of cell i in cell coordinates, OpenCV order
+    virtual void gftt(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out) = 0;
+    std::vector<Feature> extractFeatures(Frame& src, int max) override;
+    std::vector<std::vector<Feature>> extractGrid(std::vector<Frame>& cells, int max) override;
+};
+class ShiTomasiExtractorBase : public BaseFeatureExtractor {     // ShiTomasiFeatureExtractor
+public:
+    double quality = 0.4;
+    virtual void shitomasi(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out,
+                           std::vector<std::vector<double>>& score) = 0;
+    std::vector<Feature> extractFeatures(Frame& src, int max) override;
+    std::vector<std::vector<Feature>> extractGrid(std::vector<Frame>& cells, int max) override;
+};
+class LucasKanadeFMBase : public BaseFeatureMatcher {            // OpenCVLucasKanadeFM (win 32, 4 levels)
+public:
+    virtual void pyrlk(const ImageView& prev, const ImageView& next, const float* prev_xy, int n, float* next_xy,
+                       uint8_t* status, float* err) = 0;
+    fmap matchFeatures(Frame& src, Frame& next) override;
+};
+class EPnPSolverBase : public BasePnPSolver {                    // OpenCVEPnPSolver
+public:
+    OdometryPipeline* tracker = nullptr;
+    // cv::solvePnPRansac(obj, img, K, noDist, rvec, tvec, true, 100, 8, .99, inliers); returns false on failure
+    virtual bool pnp_ransac(const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec,
+                            std::vector<int>& inliers) = 0;
+    void solvePnP(Frame& src, Frame& next, Mat3& R, Vec3& t) override;
+};
+class FivePointTri : public BaseTriangulator {                   // OpenCVFivePointTri (host)
+public:
+    OdometryPipeline* tracker = nullptr;
+    void triangulate(Frame& src, Frame& next, Mat3& R, Vec3& t) override;
+};
+class BundleAdjustmentBase : public BaseOptimizer {              // CeresBundleAdjustment
+public:
+    OdometryPipeline* tracker = nullptr;
+    // ceres::Solve on cams (nc x 6: [aa(R^T), -t]) and pts (np x 3); in place
+    virtual void ba_solve(double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
+                          const int* pt_idx, int n_obs, const double* K, double huber, int max_iterations) = 0;
+    void apply(Frame& src) override;
+};
+
+// per-call statistics for the bench (not part of any result)
+struct Stats {
+    long lk_calls = 0, lk_points = 0, detect_calls = 0, pnp_calls = 0, pnp_points = 0, tri_calls = 0, ba_calls = 0, ba_obs = 0, ba_points = 0;
+    long heuristic_motion = 0;
+};
+
+class OdometryPipeline {
+public:
+    Config cfg;
+    double scale = 1;
+    int init_offset = 0;
+    double camera[9];                       // row-major 3x3
+    std::vector<ImageView> images;          // the sequence ("file_names"): decoded gray frames
+    std::vector<Vec3> gt_t;                 // ground-truth positions (parsePoses), used for scale only (Q11)
+    std::vector<std::shared_ptr<Feature3D>> feats3d;
+    std::vector<std::shared_ptr<Frame>> frames;
+    std::vector<Mat3> R, R_s;
+    std::vector<Vec3> t, t_s;
+    BaseFeatureExtractor* extractor = nullptr;
+    BaseFeatureMatcher* matcher = nullptr;
+    BasePnPSolver* pnpsolver = nullptr;
+    BaseTriangulator* triangulator = nullptr;
+    BaseOptimizer* ba = nullptr;
+    Stats stats;
+    int next_landmark_id = 0;
+
+    struct GridSection { int x, y; Frame frame; };
+
+    void initialise();                                  // :428-482
+    void addFrame(Frame& frame);                        // :329-374
+    void estimatePose(Frame& src, Frame& next);         // :376-426
+    void motionHeuristics(Mat3& _R, Vec3& _t, int j);   // :171-208
+    std::vector<GridSection> getGridROI(Frame& fr);     // :674-693
+    static double standardDeviation(const std::vector<double>& val);   // :660-672
+    static double calcYRotation(const Mat3& R, bool flip = false);     // OdometryPipeline.h:89-108
+    // startPipeline (:247-264) without GUI: sequential schedule (front-end then the lag-2 back-end job)
+    void run();
+    // same results, the reference's two threads (front-end / back-end) with a job queue
+    void run_threaded();
+    std::function<void(int)> on_frame_added;            // optional hook (e.g. bench progress)
+};
+
+// cv::Rodrigues both ways (host copy for the adapters)
+void rodrigues_v2m(const double r[3], double R[9]);
+void rodrigues_m2v(const double R[9], double r[3]);
+
+}  // namespace vo

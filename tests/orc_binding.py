@@ -81,3 +81,58 @@ def load():
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
         _cached = Oracle(C.CDLL(so))
     return _cached
+
+
+class PipelineParams(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("w", C.c_int), ("h", C.c_int), ("min_tracked_features", C.c_int),
+                ("tracked_features_tol", C.c_int), ("init_frames", C.c_int), ("bundle_size", C.c_int),
+                ("ba_iterations", C.c_int), ("extractor", C.c_int), ("threaded", C.c_int), ("n_threads", C.c_int),
+                ("reserved", C.c_int)]
+
+
+class PipelineResult:
+    """poses (n,12: R row-major then t), per-frame feature triples (col,row,landmark) in container order, stats"""
+
+    def __init__(self, lib, prefix, handle):
+        g = lambda name: getattr(lib, prefix + name)
+        n = g("num_poses")(handle)
+        self.poses = np.zeros((n, 12), np.float64)
+        if n:
+            g("get_poses")(handle, _p(self.poses, _f64p))
+        nf = g("num_frames")(handle)
+        self.features = []
+        for k in range(nf):
+            c = g("frame_feature_count")(handle, k)
+            a = np.zeros((c, 3), np.int32)
+            if c:
+                g("get_frame_features")(handle, k, _p(a, _i32p))
+            self.features.append(a)
+        st = np.zeros(16, np.float64)
+        g("get_stats")(handle, _p(st, _f64p))
+        keys = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
+                "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale"]
+        self.stats = dict(zip(keys, st[:len(keys)]))
+
+
+def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5, ba_iterations=5,
+                 extractor=0, threaded=0, n_threads=1):
+    o = load()
+    lib = o.lib
+    lib.orc_pipeline_run.restype = C.c_void_p
+    for f in ("orc_pipeline_free", "orc_pipeline_num_poses", "orc_pipeline_get_poses", "orc_pipeline_num_frames",
+              "orc_pipeline_frame_feature_count", "orc_pipeline_get_frame_features", "orc_pipeline_get_stats"):
+        getattr(lib, f).argtypes = [C.c_void_p] + ([C.c_int] if "frame_f" in f or "get_frame" in f else [])
+    lib.orc_pipeline_get_poses.argtypes = [C.c_void_p, _f64p]
+    lib.orc_pipeline_get_frame_features.argtypes = [C.c_void_p, C.c_int, _i32p]
+    lib.orc_pipeline_get_stats.argtypes = [C.c_void_p, _f64p]
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = frames.shape
+    P = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
+                       n_threads, 0)
+    Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+    gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n, 12)
+    lib.orc_pipeline_run.argtypes = [C.POINTER(PipelineParams), _u8p, _f64p, _f64p]
+    hnd = lib.orc_pipeline_run(C.byref(P), _p(frames, _u8p), _p(Kd, _f64p), _p(gt, _f64p))
+    res = PipelineResult(lib, "orc_pipeline_", hnd)
+    lib.orc_pipeline_free(hnd)
+    return res
