@@ -60,6 +60,71 @@ inline void jacobi_eig(double* A, int n, double* w, double* V, int max_sweeps = 
     }
 }
 
+
+// Symmetric eigen-decomposition with the PARALLEL (round-robin) Jacobi ordering, n even (used for EPnP's 12x12 M^T M).
+// One round = n/2 disjoint rotations whose angles are all taken from the matrix at the start of the round, applied as
+//   B = A J (columns), A' = J^T B (rows), V' = V J,
+// every element update being the two-term expression written below. This is the FIXED eigen-solver of this restatement
+// for the 12x12 case: a wavefront evaluates a round with one lane per element and obtains the same bits.
+// Round r (0..n-2) pairs: (n-1, r) and ((r+k) mod (n-1), (r-k) mod (n-1)) for k = 1..n/2-1, each ordered p < q.
+inline void jacobi_eig_parallel(double* A, int n, double* w, double* V, int max_sweeps = 30) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    std::vector<double> B((size_t)n * n);
+    std::vector<int> P(n / 2), Q(n / 2);
+    std::vector<double> C(n / 2), S(n / 2);
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        int rotated = 0;
+        for (int r = 0; r < n - 1; r++) {
+            for (int g = 0; g < n / 2; g++) {
+                int a, b;
+                if (g == 0) { a = n - 1; b = r; }
+                else { a = (r + g) % (n - 1); b = (r - g + (n - 1)) % (n - 1); }
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                P[g] = p; Q[g] = q;
+                const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
+                if (apq == 0.0 || std::fabs(apq) <= 1e-18 * (std::fabs(app) + std::fabs(aqq))) { C[g] = 1.0; S[g] = 0.0; continue; }
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                C[g] = 1.0 / std::sqrt(t * t + 1.0);
+                S[g] = t * C[g];
+                rotated++;
+            }
+            // B = A J
+            for (int i = 0; i < n; i++)
+                for (int g = 0; g < n / 2; g++) {
+                    const double x = A[i * n + P[g]], y = A[i * n + Q[g]];
+                    B[i * n + P[g]] = C[g] * x - S[g] * y;
+                    B[i * n + Q[g]] = S[g] * x + C[g] * y;
+                }
+            // A = J^T B
+            for (int j = 0; j < n; j++)
+                for (int g = 0; g < n / 2; g++) {
+                    const double x = B[P[g] * n + j], y = B[Q[g] * n + j];
+                    A[P[g] * n + j] = C[g] * x - S[g] * y;
+                    A[Q[g] * n + j] = S[g] * x + C[g] * y;
+                }
+            // V = V J
+            for (int i = 0; i < n; i++)
+                for (int g = 0; g < n / 2; g++) {
+                    const double x = V[i * n + P[g]], y = V[i * n + Q[g]];
+                    V[i * n + P[g]] = C[g] * x - S[g] * y;
+                    V[i * n + Q[g]] = S[g] * x + C[g] * y;
+                }
+        }
+        if (!rotated) break;
+    }
+    for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+    for (int i = 0; i < n - 1; i++) {
+        int mi = i;
+        for (int j = i + 1; j < n; j++) if (w[j] < w[mi]) mi = j;
+        if (mi != i) {
+            std::swap(w[i], w[mi]);
+            for (int k = 0; k < n; k++) std::swap(V[k * n + i], V[k * n + mi]);
+        }
+    }
+}
+
 // 3x3 SVD A = U diag(s) V^T via eigen-decomposition of A^T A (s descending). Rank-deficient columns of U are
 // completed by cross products. A row-major.
 inline void svd3(const double A[9], double U[9], double s[3], double V[9]) {

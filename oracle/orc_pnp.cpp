@@ -320,7 +320,7 @@ struct EPnP {
                 MtM[a * 12 + b] = MtM[b * 12 + a] = acc;
             }
         double w[12], V[144], v4[48];
-        jacobi_eig(MtM, 12, w, V);
+        jacobi_eig_parallel(MtM, 12, w, V);
         for (int i = 0; i < 4; i++)
             for (int k = 0; k < 12; k++) v4[i * 12 + k] = V[k * 12 + i];   // i-th smallest eigenvector
         double L[60], rho[6];

@@ -1,0 +1,26 @@
+// Back-end (PnP / BA) launch interfaces shared by backend*.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pmv {
+
+struct BAArgs {
+    // problem (device)
+    double* cams; double* pts; const double* obs; const int* cam_idx; const int* pt_idx; const double* K;
+    const int* pobs_start; const int* pobs_list; const int* cobs_start; const int* cobs_list;
+    int nc, np, nobs, max_iterations;
+    double huber;
+    // workspaces (device)
+    double *x, *cand, *scale, *diag, *D2, *step, *res, *J, *Einv, *gp, *Yd, *Wd, *S, *rhs, *Gpart, *summary;
+    int ldw, krows, tiles_r, tiles_c, kslices, kper, gp_rows;
+};
+
+hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,
+                               const int* pt_idx, int nobs, const double* K, double* out_r, double* out_J);
+hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A);
+hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
+                      int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
+                      double* d_rt_out, int* d_inliers, int* d_info);
+
+}  // namespace pmv

@@ -1,0 +1,582 @@
+// gfx950 bundle adjustment: ProjectionResidual + analytic Jacobians (ProjectionResidual.h:38-58) and the whole
+// Levenberg–Marquardt solve that the reference delegates to ceres::Solve (CeresBundleAdjustment.cpp:50-61), resident on the
+// device: ONE launch runs every LM iteration (no host round trip per iteration).
+//
+// Structure of one iteration (one 512-thread workgroup; all cross-thread sums use a fixed tree => run-to-run bitwise
+// reproducible):
+//   evaluate r, J (Huber corrector)  ->  Jacobi column scaling  ->  LM diagonal  ->  per-camera blocks U_c, rhs_c  ->
+//   per-point blocks: E_p^-1, g_p, W_p = Jc^T Jp, Y_p = W_p E_p^-1 written as dense rows of Yd / [Wd | g]  ->
+//   Schur complement  S -= Yd^T Wd,  rhs -= Yd^T g   as ONE dense contraction on FP64 MFMA (v_mfma_f64_16x16x4_f64)  ->
+//   Cholesky of the reduced camera matrix -> back-substitution -> model cost change -> candidate cost -> accept/reject.
+#include "pmv_ctx.h"
+#include "backend.h"
+#include <float.h>
+
+namespace pmv {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int BA_T = 512;
+constexpr int BA_NW = BA_T / 64;
+
+// ---- ceres::AngleAxisRotatePoint + exact derivatives (both branches) -------------------------------------------------
+__device__ inline void angle_axis_rotate(const double a[3], const double q[3], double p[3], double dpdw[9], double Rm[9], bool jac) {
+    const double theta2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    if (theta2 > DBL_EPSILON) {
+        const double theta = sqrt(theta2);
+        const double ct = cos(theta), st = sin(theta), ti = 1.0 / theta;
+        const double w[3] = {a[0] * ti, a[1] * ti, a[2] * ti};
+        const double wxq[3] = {w[1] * q[2] - w[2] * q[1], w[2] * q[0] - w[0] * q[2], w[0] * q[1] - w[1] * q[0]};
+        const double wq = w[0] * q[0] + w[1] * q[1] + w[2] * q[2];
+        const double tmp = wq * (1.0 - ct);
+#pragma unroll
+        for (int i = 0; i < 3; i++) p[i] = q[i] * ct + wxq[i] * st + w[i] * tmp;
+        if (!jac) return;
+        const double c1 = 1.0 - ct;
+        Rm[0] = ct + c1 * w[0] * w[0];        Rm[1] = c1 * w[0] * w[1] - st * w[2]; Rm[2] = c1 * w[0] * w[2] + st * w[1];
+        Rm[3] = c1 * w[1] * w[0] + st * w[2]; Rm[4] = ct + c1 * w[1] * w[1];        Rm[5] = c1 * w[1] * w[2] - st * w[0];
+        Rm[6] = c1 * w[2] * w[0] - st * w[1]; Rm[7] = c1 * w[2] * w[1] + st * w[0]; Rm[8] = ct + c1 * w[2] * w[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double dwk[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) dwk[i] = ((i == k ? 1.0 : 0.0) - w[i] * w[k]) * ti;
+            const double dwxq[3] = {dwk[1] * q[2] - dwk[2] * q[1], dwk[2] * q[0] - dwk[0] * q[2], dwk[0] * q[1] - dwk[1] * q[0]};
+            const double dwq = dwk[0] * q[0] + dwk[1] * q[1] + dwk[2] * q[2];
+            const double dct = -st * w[k], dst = ct * w[k];
+            const double dtmp = dwq * (1.0 - ct) + wq * (st * w[k]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) dpdw[i * 3 + k] = q[i] * dct + dwxq[i] * st + wxq[i] * dst + dwk[i] * tmp + w[i] * dtmp;
+        }
+    } else {
+        const double wxq[3] = {a[1] * q[2] - a[2] * q[1], a[2] * q[0] - a[0] * q[2], a[0] * q[1] - a[1] * q[0]};
+#pragma unroll
+        for (int i = 0; i < 3; i++) p[i] = q[i] + wxq[i];
+        if (!jac) return;
+        dpdw[0] = 0;     dpdw[1] = q[2];  dpdw[2] = -q[1];
+        dpdw[3] = -q[2]; dpdw[4] = 0;     dpdw[5] = q[0];
+        dpdw[6] = q[1];  dpdw[7] = -q[0]; dpdw[8] = 0;
+        Rm[0] = 1;     Rm[1] = -a[2]; Rm[2] = a[1];
+        Rm[3] = a[2];  Rm[4] = 1;     Rm[5] = -a[0];
+        Rm[6] = -a[1]; Rm[7] = a[0];  Rm[8] = 1;
+    }
+}
+
+// r[2]; Jc[12] = rows (du/d[aa,t']), Jp[6]
+__device__ inline void projection_residual(const double* cam, const double* X, double ox, double oy, const double* K,
+                                           double r[2], double* Jc, double* Jp, bool jac) {
+    const double fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+    const double q[3] = {X[0] + cam[3], X[1] + cam[4], X[2] + cam[5]};
+    double p[3], dpdw[9], Rm[9];
+    angle_axis_rotate(cam, q, p, dpdw, Rm, jac);
+    const double pz = p[2] * -1.0;
+    const double u = p[0] / pz * fx + cx, v = p[1] / pz * fy + cy;
+    r[0] = ox - u;
+    r[1] = oy - v;
+    if (!jac) return;
+    const double ipz = 1.0 / pz;
+    const double du[3] = {fx * ipz, 0.0, fx * p[0] * ipz * ipz};
+    const double dv[3] = {0.0, fy * ipz, fy * p[1] * ipz * ipz};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double ju_w = du[0] * dpdw[0 * 3 + k] + du[1] * dpdw[1 * 3 + k] + du[2] * dpdw[2 * 3 + k];
+        const double jv_w = dv[0] * dpdw[0 * 3 + k] + dv[1] * dpdw[1 * 3 + k] + dv[2] * dpdw[2 * 3 + k];
+        const double ju_q = du[0] * Rm[0 * 3 + k] + du[1] * Rm[1 * 3 + k] + du[2] * Rm[2 * 3 + k];
+        const double jv_q = dv[0] * Rm[0 * 3 + k] + dv[1] * Rm[1 * 3 + k] + dv[2] * Rm[2 * 3 + k];
+        Jc[k] = -ju_w; Jc[6 + k] = -jv_w; Jc[3 + k] = -ju_q; Jc[9 + k] = -jv_q;
+        Jp[k] = -ju_q; Jp[3 + k] = -jv_q;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ba_residuals(const double* __restrict__ cams, const double* __restrict__ pts,
+                                                      const double* __restrict__ obs, const int* __restrict__ cam_idx,
+                                                      const int* __restrict__ pt_idx, int nobs, const double* __restrict__ K,
+                                                      double* __restrict__ out_r, double* __restrict__ out_J) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nobs) return;
+    double r[2], Jc[12], Jp[6];
+    projection_residual(cams + 6 * cam_idx[i], pts + 3 * pt_idx[i], obs[2 * i], obs[2 * i + 1], K, r, Jc, Jp, true);
+    out_r[2 * i] = r[0]; out_r[2 * i + 1] = r[1];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) out_J[i * 18 + rr * 9 + k] = Jc[rr * 6 + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) out_J[i * 18 + rr * 9 + 6 + k] = Jp[rr * 3 + k];
+    }
+}
+
+// ---- deterministic block reductions -----------------------------------------------------------------------------------
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// every thread gets the sum; red: BA_NW doubles of LDS
+__device__ inline double block_sum(double v, double* red) {
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int i = 1; i < BA_NW; i++) s += red[i];
+    return s;
+}
+__device__ inline double block_max(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int i = 1; i < BA_NW; i++) s = fmax(s, red[i]);
+    return s;
+}
+
+struct BAState {   // in LDS
+    double x_cost, cand_cost, x_norm, radius, decrease, gmax, model_change, step_norm;
+    int iter, reuse_diag, invalid, need_eval, done, termination, successful, chol_fail, first;
+};
+
+__device__ inline void huber_rho(double s, double a, double& rho0, double& rho1) {
+    const double b = a * a;
+    if (s > b) {
+        const double r = sqrt(s);
+        rho0 = 2 * a * r - b;
+        rho1 = fmax(DBL_MIN, a / r);
+    } else { rho0 = s; rho1 = 1; }
+}
+
+__global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
+    __shared__ double red[BA_NW];
+    __shared__ double cred[BA_NW * 27];
+    __shared__ BAState st;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nc = A.nc, np = A.np, nobs = A.nobs;
+    const int n = 6 * nc + 3 * np, m = 6 * nc;
+    const int ldw = A.ldw;          // row stride of Yd / Wd (multiple of 16, >= m + 1)
+    const int krows = A.krows;      // 3*np padded to a multiple of 4
+    double* x = A.x; double* cand = A.cand; double* scale = A.scale; double* diag = A.diag; double* D2 = A.D2;
+    double* step = A.step; double* res = A.res; double* J = A.J; double* Einv = A.Einv; double* gp = A.gp;
+    double* Yd = A.Yd; double* Wd = A.Wd; double* S = A.S; double* rhs = A.rhs; double* Gp = A.Gpart;
+
+    // x <- [cams | pts]
+    for (int i = tid; i < 6 * nc; i += BA_T) x[i] = A.cams[i];
+    for (int i = tid; i < 3 * np; i += BA_T) x[6 * nc + i] = A.pts[i];
+    if (tid == 0) {
+        st.radius = 1e4; st.decrease = 2.0; st.iter = 0; st.reuse_diag = 0; st.invalid = 0; st.need_eval = 1; st.done = 0;
+        st.termination = 0; st.successful = 0; st.chol_fail = 0; st.first = 1; st.gmax = 0; st.x_cost = 0;
+    }
+    __syncthreads();
+
+    for (;;) {
+        // ================= (re-)evaluate cost, corrected residuals and Jacobians at x ======================================
+        if (st.need_eval) {
+            double cpart = 0;
+            for (int i = tid; i < nobs; i += BA_T) {
+                double r[2], Jc[12], Jp[6];
+                const int c = A.cam_idx[i], p = A.pt_idx[i];
+                projection_residual(x + 6 * c, x + 6 * nc + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, Jc, Jp, true);
+                double rho0, rho1;
+                huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
+                cpart += 0.5 * rho0;
+                const double sr = sqrt(rho1);
+                res[2 * i] = r[0] * sr; res[2 * i + 1] = r[1] * sr;
+                if (st.first) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) J[(size_t)i * 18 + k] = Jc[k] * sr;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) J[(size_t)i * 18 + 12 + k] = Jp[k] * sr;
+                } else {   // Jacobi scaling is fixed after the first evaluation
+                    const double* sc = scale + 6 * c;
+                    const double* sp = scale + 6 * nc + 3 * p;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) J[(size_t)i * 18 + k] = Jc[k] * sr * sc[k % 6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) J[(size_t)i * 18 + 12 + k] = Jp[k] * sr * sp[k % 3];
+                }
+            }
+            const double xc = block_sum(cpart, red);
+            double xn = 0;
+            for (int i = tid; i < n; i += BA_T) xn += x[i] * x[i];
+            xn = block_sum(xn, red);
+            if (tid == 0) { st.x_cost = xc; st.x_norm = sqrt(xn); if (st.first) A.summary[0] = xc; }
+            __syncthreads();
+            if (st.first) {
+                // jacobian column norms -> scale = 1/(1+||col||); cameras by tree reduction, points by their obs lists
+                for (int c = 0; c < nc; c++) {
+                    double acc[6] = {0, 0, 0, 0, 0, 0};
+                    for (int e = A.cobs_start[c] + tid; e < A.cobs_start[c + 1]; e += BA_T) {
+                        const double* Jc = J + (size_t)A.cobs_list[e] * 18;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) acc[k] += Jc[k] * Jc[k] + Jc[6 + k] * Jc[6 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const double s = block_sum(acc[k], red);
+                        if (tid == 0) scale[6 * c + k] = 1.0 / (1.0 + sqrt(s));
+                    }
+                }
+                for (int p = tid; p < np; p += BA_T) {
+                    double acc[3] = {0, 0, 0};
+                    for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
+                        const double* Jp = J + (size_t)A.pobs_list[e] * 18 + 12;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) acc[k] += Jp[k] * Jp[k] + Jp[3 + k] * Jp[3 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; k++) scale[6 * nc + 3 * p + k] = 1.0 / (1.0 + sqrt(acc[k]));
+                }
+                __syncthreads();
+                for (int i = tid; i < nobs; i += BA_T) {
+                    const double* sc = scale + 6 * A.cam_idx[i];
+                    const double* sp = scale + 6 * nc + 3 * A.pt_idx[i];
+#pragma unroll
+                    for (int k = 0; k < 12; k++) J[(size_t)i * 18 + k] *= sc[k % 6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) J[(size_t)i * 18 + 12 + k] *= sp[k % 3];
+                }
+            }
+            if (tid == 0) { st.need_eval = 0; st.first = 0; st.gmax = -1.0; }
+            __syncthreads();
+        }
+        // ================= loop-top termination tests (FinalizeIterationAndCheckIfMinimizerCanContinue) ======================
+        // (gmax is produced by the Schur phase below; on the first pass it is not known yet and is checked after that phase)
+        if (tid == 0) {
+            if (st.iter >= A.max_iterations) { st.done = 1; st.termination = 0; }
+            else if (st.gmax >= 0 && st.gmax <= 1e-10) { st.done = 1; st.termination = 2; }
+            else if (st.radius < 1e-32) { st.done = 1; st.termination = 4; }
+        }
+        __syncthreads();
+        if (st.done) break;
+
+        // ================= camera blocks: U_c = sum Jc^T Jc, rhs_c = sum Jc^T r (tree reductions) ===========================
+        for (int i = tid; i < m * m; i += BA_T) S[i] = 0.0;
+        __syncthreads();
+        for (int c = 0; c < nc; c++) {
+            double acc[27];
+#pragma unroll
+            for (int k = 0; k < 27; k++) acc[k] = 0;
+            for (int e = A.cobs_start[c] + tid; e < A.cobs_start[c + 1]; e += BA_T) {
+                const int i = A.cobs_list[e];
+                const double* Jc = J + (size_t)i * 18;
+                const double r0 = res[2 * i], r1 = res[2 * i + 1];
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int b = a; b < 6; b++) acc[k++] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+                }
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[21 + a] += Jc[a] * r0 + Jc[6 + a] * r1;
+            }
+#pragma unroll
+            for (int k = 0; k < 27; k++) acc[k] = wave_sum_f64(acc[k]);
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 27; k++) cred[wid * 27 + k] = acc[k];
+            }
+            __syncthreads();
+            if (tid < 27) {
+                double s = cred[tid];
+                for (int w = 1; w < BA_NW; w++) s += cred[w * 27 + tid];
+                if (tid < 21) {
+                    int a = 0, k = tid;
+                    while (k >= 6 - a) { k -= 6 - a; a++; }
+                    const int b = a + k;
+                    S[(size_t)(6 * c + a) * m + 6 * c + b] = s;
+                    S[(size_t)(6 * c + b) * m + 6 * c + a] = s;
+                } else rhs[6 * c + (tid - 21)] = s;
+            }
+            __syncthreads();
+        }
+        // ================= LM diagonal ======================================================================================
+        if (!st.reuse_diag) {
+            for (int i = tid; i < m; i += BA_T) diag[i] = fmin(fmax(S[(size_t)i * m + i], 1e-6), 1e32);
+            for (int p = tid; p < np; p += BA_T) {
+                double acc[3] = {0, 0, 0};
+                for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
+                    const double* Jp = J + (size_t)A.pobs_list[e] * 18 + 12;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) acc[k] += Jp[k] * Jp[k] + Jp[3 + k] * Jp[3 + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) diag[m + 3 * p + k] = fmin(fmax(acc[k], 1e-6), 1e32);
+            }
+        }
+        __syncthreads();
+        {
+            const double radius = st.radius;
+            for (int i = tid; i < n; i += BA_T) D2[i] = diag[i] / radius;
+        }
+        __syncthreads();
+        for (int i = tid; i < m; i += BA_T) S[(size_t)i * m + i] += D2[i];
+        // ================= point blocks: E^-1, g, dense rows of Yd and [Wd | g] =============================================
+        for (int i = tid; i < krows * ldw; i += BA_T) { Yd[i] = 0.0; Wd[i] = 0.0; }
+        if (tid == 0) st.chol_fail = 0;
+        __syncthreads();
+        double gmax_p = 0;
+        for (int p = tid; p < np; p += BA_T) {
+            double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+            for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
+                const int i = A.pobs_list[e];
+                const double* Jp = J + (size_t)i * 18 + 12;
+                const double r0 = res[2 * i], r1 = res[2 * i + 1];
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+#pragma unroll
+                    for (int b = 0; b < 3; b++) E[a * 3 + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
+                    gv[a] += Jp[a] * r0 + Jp[3 + a] * r1;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                E[a * 3 + a] += D2[m + 3 * p + a];
+                gmax_p = fmax(gmax_p, fabs(gv[a] / scale[m + 3 * p + a]));
+            }
+            // 3x3 Cholesky inverse
+            double L[9];
+            bool ok = true;
+            {
+                double d = E[0];
+                ok = ok && (d > 0.0); L[0] = sqrt(d);
+                L[3] = E[3] / L[0]; L[6] = E[6] / L[0];
+                d = E[4] - L[3] * L[3];
+                ok = ok && (d > 0.0); L[4] = sqrt(d);
+                L[7] = (E[7] - L[6] * L[3]) / L[4];
+                d = E[8] - L[6] * L[6] - L[7] * L[7];
+                ok = ok && (d > 0.0); L[8] = sqrt(d);
+            }
+            if (!ok) { st.chol_fail = 1; continue; }
+            double Ei[9];
+#pragma unroll
+            for (int cI = 0; cI < 3; cI++) {
+                double e0 = (cI == 0) ? 1.0 : 0.0, e1 = (cI == 1) ? 1.0 : 0.0, e2 = (cI == 2) ? 1.0 : 0.0;
+                e0 = e0 / L[0];
+                e1 = (e1 - L[3] * e0) / L[4];
+                e2 = (e2 - L[6] * e0 - L[7] * e1) / L[8];
+                e2 = e2 / L[8];
+                e1 = (e1 - L[7] * e2) / L[4];
+                e0 = (e0 - L[3] * e1 - L[6] * e2) / L[0];
+                Ei[0 * 3 + cI] = e0; Ei[1 * 3 + cI] = e1; Ei[2 * 3 + cI] = e2;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) Einv[(size_t)p * 9 + k] = Ei[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { gp[(size_t)p * 3 + k] = gv[k]; Wd[(size_t)(3 * p + k) * ldw + m] = gv[k]; }
+            for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
+                const int i = A.pobs_list[e];
+                const int c = A.cam_idx[i];
+                const double* Jc = J + (size_t)i * 18;
+                const double* Jp = Jc + 12;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    double w3[3];
+#pragma unroll
+                    for (int b = 0; b < 3; b++) w3[b] = Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b];
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        const double y = w3[0] * Ei[0 * 3 + b] + w3[1] * Ei[1 * 3 + b] + w3[2] * Ei[2 * 3 + b];
+                        Wd[(size_t)(3 * p + b) * ldw + 6 * c + a] += w3[b];
+                        Yd[(size_t)(3 * p + b) * ldw + 6 * c + a] += y;
+                    }
+                }
+            }
+        }
+        // gradient max norm of the unscaled problem (cameras from rhs, points from g)
+        for (int i = tid; i < m; i += BA_T) gmax_p = fmax(gmax_p, fabs(rhs[i] / scale[i]));
+        const double gm = block_max(gmax_p, red);
+        if (tid == 0 && st.gmax < 0) st.gmax = gm;
+        __syncthreads();
+        if (st.gmax <= 1e-10) { if (tid == 0) { st.done = 1; st.termination = 2; } __syncthreads(); break; }
+
+        bool valid = !st.chol_fail;
+        if (valid) {
+            // ================= Schur complement on FP64 MFMA: G = Yd^T [Wd | g]  (m_pad x ncol_pad, K = krows) =============
+            const int tr = A.tiles_r, tc = A.tiles_c, ks = A.kslices, kper = A.kper;
+            const int items = tr * tc * ks;
+            for (int it = wid; it < items; it += BA_NW) {
+                const int s = it / (tr * tc), tile = it - s * (tr * tc);
+                const int ti = tile / tc, tj = tile - ti * tc;
+                const int k0 = s * kper, k1 = min(krows, k0 + kper);
+                v4d acc = {0, 0, 0, 0};
+                const double* ya = Yd + (size_t)(lane >> 4) * ldw + ti * 16 + (lane & 15);
+                const double* wb = Wd + (size_t)(lane >> 4) * ldw + tj * 16 + (lane & 15);
+                for (int k = k0; k < k1; k += 4) {
+                    const double a = ya[(size_t)k * ldw];
+                    const double b = wb[(size_t)k * ldw];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+                // D[row = (lane>>4) + 4*reg][col = lane&15]
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    Gp[((size_t)s * A.gp_rows + ti * 16 + (lane >> 4) + 4 * r) * ldw + tj * 16 + (lane & 15)] = acc[r];
+            }
+            __syncthreads();
+            for (int i = tid; i < m * (m + 1); i += BA_T) {
+                const int a = i / (m + 1), b = i - a * (m + 1);
+                double g = 0;
+                for (int s = 0; s < ks; s++) g += Gp[((size_t)s * A.gp_rows + a) * ldw + b];
+                if (b < m) S[(size_t)a * m + b] -= g;
+                else rhs[a] -= g;
+            }
+            __syncthreads();
+            // ================= Cholesky of S (right-looking, in place, lower) ================================================
+            for (int j = 0; j < m; j++) {
+                if (tid == 0) {
+                    const double d = S[(size_t)j * m + j];
+                    if (!(d > 0.0)) st.chol_fail = 1;
+                    else S[(size_t)j * m + j] = sqrt(d);
+                }
+                __syncthreads();
+                if (st.chol_fail) break;
+                const double dj = S[(size_t)j * m + j];
+                for (int i = j + 1 + tid; i < m; i += BA_T) S[(size_t)i * m + j] /= dj;
+                __syncthreads();
+                const int rem = m - j - 1;
+                for (int e = tid; e < rem * rem; e += BA_T) {
+                    const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+                    if (k <= i) S[(size_t)i * m + k] -= S[(size_t)i * m + j] * S[(size_t)k * m + j];
+                }
+                __syncthreads();
+            }
+            valid = !st.chol_fail;
+        }
+        if (valid) {
+            // forward / backward substitution (thread 0; m <= 192)
+            if (tid == 0) {
+                for (int i = 0; i < m; i++) {
+                    double v = rhs[i];
+                    for (int k = 0; k < i; k++) v -= S[(size_t)i * m + k] * step[k];
+                    step[i] = v / S[(size_t)i * m + i];
+                }
+                for (int i = m - 1; i >= 0; i--) {
+                    double v = step[i];
+                    for (int k = i + 1; k < m; k++) v -= S[(size_t)k * m + i] * step[k];
+                    step[i] = v / S[(size_t)i * m + i];
+                }
+            }
+            __syncthreads();
+            // point back-substitution: y_p = E^-1 (g_p - sum W^T y_c)
+            for (int p = tid; p < np; p += BA_T) {
+                double t3[3] = {gp[(size_t)p * 3], gp[(size_t)p * 3 + 1], gp[(size_t)p * 3 + 2]};
+                for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
+                    const int i = A.pobs_list[e];
+                    const int c = A.cam_idx[i];
+                    const double* Jc = J + (size_t)i * 18;
+                    const double* Jp = Jc + 12;
+                    double jy0 = 0, jy1 = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) { jy0 += Jc[a] * step[6 * c + a]; jy1 += Jc[6 + a] * step[6 * c + a]; }
+#pragma unroll
+                    for (int a = 0; a < 3; a++) t3[a] -= Jp[a] * jy0 + Jp[3 + a] * jy1;
+                }
+                const double* Ei = Einv + (size_t)p * 9;
+#pragma unroll
+                for (int a = 0; a < 3; a++) step[m + 3 * p + a] = Ei[a * 3] * t3[0] + Ei[a * 3 + 1] * t3[1] + Ei[a * 3 + 2] * t3[2];
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += BA_T) step[i] = -step[i];
+            __syncthreads();
+            // model cost change = -(J step)^T (r + J step / 2)
+            double mc = 0;
+            for (int i = tid; i < nobs; i += BA_T) {
+                const int c = A.cam_idx[i], p = A.pt_idx[i];
+                const double* Jr = J + (size_t)i * 18;
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    double mr = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) mr += Jr[rr * 6 + k] * step[6 * c + k];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) mr += Jr[12 + rr * 3 + k] * step[m + 3 * p + k];
+                    mc -= mr * (res[2 * i + rr] + mr / 2.0);
+                }
+            }
+            mc = block_sum(mc, red);
+            if (tid == 0) st.model_change = mc;
+            __syncthreads();
+            valid = st.model_change > 0.0;
+        }
+        if (tid == 0) st.iter++;
+        if (!valid) {   // HandleInvalidStep
+            if (tid == 0) {
+                if (++st.invalid >= 5) { st.done = 1; st.termination = 4; }
+                else { st.radius /= st.decrease; st.decrease *= 2; st.reuse_diag = 1; }
+            }
+            __syncthreads();
+            if (st.done) break;
+            continue;
+        }
+        // ================= candidate, tolerances, accept / reject =============================================================
+        double sn = 0;
+        for (int i = tid; i < n; i += BA_T) {
+            const double d = step[i] * scale[i];
+            cand[i] = x[i] + d;
+            sn += d * d;
+        }
+        sn = block_sum(sn, red);
+        double cpart = 0;
+        for (int i = tid; i < nobs; i += BA_T) {
+            double r[2];
+            const int c = A.cam_idx[i], p = A.pt_idx[i];
+            projection_residual(cand + 6 * c, cand + 6 * nc + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, nullptr, nullptr, false);
+            double rho0, rho1;
+            huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
+            cpart += 0.5 * rho0;
+        }
+        const double cc = block_sum(cpart, red);
+        if (tid == 0) {
+            st.invalid = 0;
+            st.cand_cost = cc;
+            st.step_norm = sqrt(sn);
+            const double cost_change = st.x_cost - cc;
+            if (st.step_norm <= 1e-8 * (st.x_norm + 1e-8)) { st.done = 1; st.termination = 3; }
+            else if (fabs(cost_change) <= 1e-6 * st.x_cost) { st.done = 1; st.termination = 1; }
+            else {
+                const double rel = cost_change / st.model_change;
+                if (rel > 1e-3) {
+                    st.need_eval = 2;   // accept: x <- cand below
+                    st.successful++;
+                    const double t = 2.0 * rel - 1.0;
+                    st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+                    st.radius = fmin(1e16, st.radius);
+                    st.decrease = 2.0;
+                    st.reuse_diag = 0;
+                } else {
+                    st.radius /= st.decrease; st.decrease *= 2; st.reuse_diag = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (st.done) break;
+        if (st.need_eval == 2) {
+            for (int i = tid; i < n; i += BA_T) x[i] = cand[i];
+            __syncthreads();
+            if (tid == 0) st.need_eval = 1;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 6 * nc; i += BA_T) A.cams[i] = x[i];
+    for (int i = tid; i < 3 * np; i += BA_T) A.pts[i] = x[6 * nc + i];
+    if (tid == 0) {
+        A.summary[1] = st.x_cost; A.summary[2] = st.iter; A.summary[3] = st.successful; A.summary[4] = st.termination;
+    }
+}
+
+hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,
+                               const int* pt_idx, int nobs, const double* K, double* out_r, double* out_J) {
+    if (nobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ba_residuals, dim3((nobs + 255) / 256), dim3(256), 0, s, cams, pts, obs, cam_idx, pt_idx, nobs, K, out_r, out_J);
+    return hipGetLastError();
+}
+hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A) {
+    hipLaunchKernelGGL(k_ba_lm, dim3(1), dim3(BA_T), 0, s, A);
+    return hipGetLastError();
+}
+
+}  // namespace pmv

@@ -1,0 +1,781 @@
+// gfx950 PnP: batched RANSAC hypotheses (5-point EPnP, one wavefront per hypothesis), inlier scoring (hypothesis x point
+// grid), the sequential RANSAC bookkeeping (adaptive iteration cut-off) replayed on the device, and the Levenberg–Marquardt
+// refit on the inliers — everything cv::solvePnPRansac does behind /root/reference/OpenCVEPnPSolver.cpp:35-36.
+// The sample index stream (cv::RNG((uint64)-1), 5 distinct indices per iteration) depends only on the point count, so the
+// host adapter generates all `iterations` samples up front; evaluating them in parallel and then replaying the
+// "best so far / niters = RANSACUpdateNumIters(...)" scan in iteration order gives exactly the sequential result.
+#include "pmv_ctx.h"
+#include "backend.h"
+#include <float.h>
+
+namespace pmv {
+
+// ---- small dense routines (device copies of the fixed-choice algorithms documented in DESIGN.md) -------------------------
+__device__ inline void d_jacobi_eig(double* A, int n, double* w, double* V) {   // cyclic Jacobi, ascending eigenvalues
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        int rotated = 0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double app = A[p * n + p], aqq = A[q * n + q];
+                if (fabs(apq) <= 1e-18 * (fabs(app) + fabs(aqq))) { A[p * n + q] = A[q * n + p] = 0.0; continue; }
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    if (k == p || k == q) continue;
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    const double nkp = c * akp - s * akq, nkq = s * akp + c * akq;
+                    A[k * n + p] = A[p * n + k] = nkp;
+                    A[k * n + q] = A[q * n + k] = nkq;
+                }
+                A[p * n + p] = app - t * apq;
+                A[q * n + q] = aqq + t * apq;
+                A[p * n + q] = A[q * n + p] = 0.0;
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+                rotated++;
+            }
+        if (!rotated) break;
+    }
+    for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+    for (int i = 0; i < n - 1; i++) {
+        int m = i;
+        for (int j = i + 1; j < n; j++) if (w[j] < w[m]) m = j;
+        if (m != i) {
+            double t = w[i]; w[i] = w[m]; w[m] = t;
+            for (int k = 0; k < n; k++) { t = V[k * n + i]; V[k * n + i] = V[k * n + m]; V[k * n + m] = t; }
+        }
+    }
+}
+
+__device__ inline void d_svd3(const double A[9], double U[9], double s[3], double V[9]) {
+    double AtA[9], w[3], Ve[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += A[k * 3 + i] * A[k * 3 + j];
+            AtA[i * 3 + j] = acc;
+        }
+    d_jacobi_eig(AtA, 3, w, Ve);
+    for (int k = 0; k < 3; k++) {
+        const int src = 2 - k;
+        s[k] = sqrt(w[src] > 0 ? w[src] : 0.0);
+        for (int i = 0; i < 3; i++) V[i * 3 + k] = Ve[i * 3 + src];
+    }
+    for (int k = 0; k < 3; k++) {
+        double u[3];
+        for (int i = 0; i < 3; i++) u[i] = A[i * 3] * V[0 * 3 + k] + A[i * 3 + 1] * V[1 * 3 + k] + A[i * 3 + 2] * V[2 * 3 + k];
+        const double nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (nrm > 1e-12 * (s[0] > 0 ? s[0] : 1.0) && nrm > 0) {
+            for (int i = 0; i < 3; i++) U[i * 3 + k] = u[i] / nrm;
+        } else if (k == 2) {
+            U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
+            U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
+            U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
+        } else {
+            for (int i = 0; i < 3; i++) U[i * 3 + k] = (i == k) ? 1.0 : 0.0;
+        }
+    }
+}
+
+__device__ inline void d_rodrigues_v2m(const double r[3], double R[9]) {
+    const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1. / theta;
+    const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+__device__ inline void d_rodrigues_m2v(const double Rin[9], double r[3]) {
+    double U[9], s[3], V[9], R[9];
+    d_svd3(Rin, U, s, V);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = U[i * 3] * V[j * 3] + U[i * 3 + 1] * V[j * 3 + 1] + U[i * 3 + 2] * V[j * 3 + 2];
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double sn = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (sn < 1e-5) {
+        if (c > 0) { rx = ry = rz = 0; }
+        else {
+            double t;
+            t = (R[0] + 1) * 0.5; rx = sqrt(fmax(t, 0.));
+            t = (R[4] + 1) * 0.5; ry = sqrt(fmax(t, 0.)) * (R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1) * 0.5; rz = sqrt(fmax(t, 0.)) * (R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        const double vth = 1 / (2 * sn) * theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+__device__ inline void d_pinv_solve(const double* A, int m, int n, const double* b, double* x) {
+    double AtA[36], w[6], V[36], Atb[6];
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) {
+            double acc = 0;
+            for (int k = 0; k < m; k++) acc += A[k * n + i] * A[k * n + j];
+            AtA[i * n + j] = acc;
+        }
+        double acc = 0;
+        for (int k = 0; k < m; k++) acc += A[k * n + i] * b[k];
+        Atb[i] = acc;
+    }
+    d_jacobi_eig(AtA, n, w, V);
+    double ssum = 0;
+    for (int i = 0; i < n; i++) ssum += sqrt(w[i] > 0 ? w[i] : 0.0);
+    const double thr = 2 * DBL_EPSILON * ssum;
+    for (int i = 0; i < n; i++) x[i] = 0;
+    for (int k = 0; k < n; k++) {
+        const double sg = sqrt(w[k] > 0 ? w[k] : 0.0);
+        if (!(sg > thr)) continue;
+        double proj = 0;
+        for (int i = 0; i < n; i++) proj += V[i * n + k] * Atb[i];
+        proj /= w[k];
+        for (int i = 0; i < n; i++) x[i] += V[i * n + k] * proj;
+    }
+}
+
+__device__ inline double d_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ inline double d_dist2(const double* a, const double* b) {
+    return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+
+// ---- EPnP on 5 points; per-hypothesis state lives in LDS (one wavefront = one hypothesis) ---------------------------------
+struct EpnpShared {
+    double A[144], B[144], V[144];
+    double M[10 * 12];
+    double C[6], S[6];
+    int P[6], Q[6];
+    double pws[15], us[10], alphas[20], cws[12];
+    double v4[48];
+    int rotated;
+};
+
+__device__ void epnp_qr_solve(double* A, double* b, double* X) {   // epnp::qr_solve, 6x4
+    const int nr = 6, nc = 4;
+    double A1[6], A2[6];
+    double* ppAkk = A;
+    for (int k = 0; k < nc; k++) {
+        double* ppAik1 = ppAkk;
+        double eta = fabs(*ppAik1);
+        for (int i = k + 1; i < nr; i++) {
+            const double elt = fabs(*ppAik1);
+            if (eta < elt) eta = elt;
+            ppAik1 += nc;
+        }
+        if (eta == 0) { X[0] = X[1] = X[2] = X[3] = 0.0; return; }
+        double* ppAik2 = ppAkk;
+        double sum2 = 0.0;
+        const double inv_eta = 1. / eta;
+        for (int i = k; i < nr; i++) { *ppAik2 *= inv_eta; sum2 += *ppAik2 * *ppAik2; ppAik2 += nc; }
+        double sigma = sqrt(sum2);
+        if (*ppAkk < 0) sigma = -sigma;
+        *ppAkk += sigma;
+        A1[k] = sigma * *ppAkk;
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < nc; j++) {
+            double* ppAik = ppAkk;
+            double sum = 0;
+            for (int i = k; i < nr; i++) { sum += *ppAik * ppAik[j - k]; ppAik += nc; }
+            const double tau = sum / A1[k];
+            ppAik = ppAkk;
+            for (int i = k; i < nr; i++) { ppAik[j - k] -= tau * *ppAik; ppAik += nc; }
+        }
+        ppAkk += nc + 1;
+    }
+    double* ppAjj = A;
+    for (int j = 0; j < nc; j++) {
+        double* ppAij = ppAjj;
+        double tau = 0;
+        for (int i = j; i < nr; i++) { tau += *ppAij * b[i]; ppAij += nc; }
+        tau /= A1[j];
+        ppAij = ppAjj;
+        for (int i = j; i < nr; i++) { b[i] -= tau * *ppAij; ppAij += nc; }
+        ppAjj += nc + 1;
+    }
+    X[nc - 1] = b[nc - 1] / A2[nc - 1];
+    for (int i = nc - 2; i >= 0; i--) {
+        const double* ppAij = A + i * nc + (i + 1);
+        double sum = 0;
+        for (int j = i + 1; j < nc; j++) { sum += *ppAij * X[j]; ppAij++; }
+        X[i] = (b[i] - sum) / A2[i];
+    }
+}
+
+__device__ void epnp_gauss_newton(const double* L, const double* rho, double* betas) {
+    for (int k = 0; k < 5; k++) {
+        double A[24], b[6], x[4];
+        for (int i = 0; i < 6; i++) {
+            const double* rowL = L + i * 10;
+            double* rowA = A + i * 4;
+            rowA[0] = 2 * rowL[0] * betas[0] + rowL[1] * betas[1] + rowL[3] * betas[2] + rowL[6] * betas[3];
+            rowA[1] = rowL[1] * betas[0] + 2 * rowL[2] * betas[1] + rowL[4] * betas[2] + rowL[7] * betas[3];
+            rowA[2] = rowL[3] * betas[0] + rowL[4] * betas[1] + 2 * rowL[5] * betas[2] + rowL[8] * betas[3];
+            rowA[3] = rowL[6] * betas[0] + rowL[7] * betas[1] + rowL[8] * betas[2] + 2 * rowL[9] * betas[3];
+            b[i] = rho[i] - (rowL[0] * betas[0] * betas[0] + rowL[1] * betas[0] * betas[1] + rowL[2] * betas[1] * betas[1] +
+                             rowL[3] * betas[0] * betas[2] + rowL[4] * betas[1] * betas[2] + rowL[5] * betas[2] * betas[2] +
+                             rowL[6] * betas[0] * betas[3] + rowL[7] * betas[1] * betas[3] + rowL[8] * betas[2] * betas[3] +
+                             rowL[9] * betas[3] * betas[3]);
+        }
+        epnp_qr_solve(A, b, x);
+        for (int i = 0; i < 4; i++) betas[i] += x[i];
+    }
+}
+
+// compute_R_and_t for one beta set (n = 5 points); returns the mean reprojection error
+__device__ double epnp_R_and_t(const EpnpShared& sh, const double* betas, double fu, double fv, double uc, double vc,
+                               double R[9], double t[3]) {
+    const int n = 5;
+    double ccs[12], pcs[15];
+    for (int i = 0; i < 12; i++) ccs[i] = 0.0;
+    for (int i = 0; i < 4; i++) {
+        const double* v = sh.v4 + 12 * i;
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++) ccs[j * 3 + k] += betas[i] * v[3 * j + k];
+    }
+    for (int i = 0; i < n; i++) {
+        const double* a = &sh.alphas[4 * i];
+        for (int j = 0; j < 3; j++) pcs[3 * i + j] = a[0] * ccs[j] + a[1] * ccs[3 + j] + a[2] * ccs[6 + j] + a[3] * ccs[9 + j];
+    }
+    if (pcs[2] < 0.0) {
+        for (int i = 0; i < 12; i++) ccs[i] = -ccs[i];
+        for (int i = 0; i < 15; i++) pcs[i] = -pcs[i];
+    }
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) { pc0[j] += pcs[3 * i + j]; pw0[j] += sh.pws[3 * i + j]; }
+    for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        const double* pc = &pcs[3 * i];
+        const double* pw = &sh.pws[3 * i];
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    double U[9], s[3], V[9];
+    d_svd3(abt, U, s, V);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = U[i * 3] * V[j * 3] + U[i * 3 + 1] * V[j * 3 + 1] + U[i * 3 + 2] * V[j * 3 + 2];
+    const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] - R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+    if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+    t[0] = pc0[0] - d_dot3(R, pw0);
+    t[1] = pc0[1] - d_dot3(R + 3, pw0);
+    t[2] = pc0[2] - d_dot3(R + 6, pw0);
+    double sum2 = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double* pw = &sh.pws[3 * i];
+        const double Xc = d_dot3(R, pw) + t[0], Yc = d_dot3(R + 3, pw) + t[1], inv_Zc = 1.0 / (d_dot3(R + 6, pw) + t[2]);
+        const double ue = uc + fu * Xc * inv_Zc, ve = vc + fv * Yc * inv_Zc;
+        const double u = sh.us[2 * i], v = sh.us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+    return sum2 / n;
+}
+
+// grid = n_hyp, block = 64. models: n_hyp x 6 (rvec, tvec)
+__global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, const float* __restrict__ img,
+                                                const int* __restrict__ samples, const double* __restrict__ K,
+                                                double* __restrict__ models) {
+    __shared__ EpnpShared sh;
+    const int h = blockIdx.x, lane = threadIdx.x;
+    const double fu = K[0], fv = K[4], uc = K[2], vc = K[5];
+    const int n = 5;
+    if (lane == 0) {
+        const double ifx = 1. / fu, ify = 1. / fv;
+        for (int i = 0; i < n; i++) {
+            const int s = samples[h * 5 + i];
+            sh.pws[3 * i] = obj[3 * s]; sh.pws[3 * i + 1] = obj[3 * s + 1]; sh.pws[3 * i + 2] = obj[3 * s + 2];
+            const float xn = (float)(((double)img[2 * s] - uc) * ifx);
+            const float yn = (float)(((double)img[2 * s + 1] - vc) * ify);
+            sh.us[2 * i] = xn * fu + uc;
+            sh.us[2 * i + 1] = yn * fv + vc;
+        }
+        // choose_control_points
+        double* cws = sh.cws;
+        cws[0] = cws[1] = cws[2] = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < 3; j++) cws[j] += sh.pws[3 * i + j];
+        for (int j = 0; j < 3; j++) cws[j] /= n;
+        double C[9], w[3], V[9];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                double acc = 0;
+                for (int i = 0; i < n; i++) acc += (sh.pws[3 * i + a] - cws[a]) * (sh.pws[3 * i + b] - cws[b]);
+                C[a * 3 + b] = acc;
+            }
+        d_jacobi_eig(C, 3, w, V);
+        for (int i = 1; i < 4; i++) {
+            const int src = 3 - i;
+            const double k = sqrt((w[src] > 0 ? w[src] : 0.0) / n);
+            for (int j = 0; j < 3; j++) cws[3 * i + j] = cws[j] + k * V[j * 3 + src];
+        }
+        // compute_barycentric_coordinates (cvInvert CV_SVD = pseudo-inverse)
+        double cc[9], U[9], s3[3], V3[9], ci[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = cws[3 * j + i] - cws[i];
+        d_svd3(cc, U, s3, V3);
+        const double thr = 2 * DBL_EPSILON * (s3[0] + s3[1] + s3[2]);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double acc = 0;
+                for (int k = 0; k < 3; k++)
+                    if (s3[k] > thr) acc += V3[i * 3 + k] * U[j * 3 + k] / s3[k];
+                ci[i * 3 + j] = acc;
+            }
+        for (int i = 0; i < n; i++) {
+            const double* pi = &sh.pws[3 * i];
+            double* a = &sh.alphas[4 * i];
+            for (int j = 0; j < 3; j++)
+                a[1 + j] = ci[3 * j] * (pi[0] - cws[0]) + ci[3 * j + 1] * (pi[1] - cws[1]) + ci[3 * j + 2] * (pi[2] - cws[2]);
+            a[0] = 1.0f - a[1] - a[2] - a[3];
+        }
+        // fill_M
+        for (int i = 0; i < n; i++) {
+            const double* as = &sh.alphas[4 * i];
+            double* M1 = &sh.M[(2 * i) * 12];
+            double* M2 = M1 + 12;
+            const double u = sh.us[2 * i], v = sh.us[2 * i + 1];
+            for (int k = 0; k < 4; k++) {
+                M1[3 * k] = as[k] * fu; M1[3 * k + 1] = 0.0; M1[3 * k + 2] = as[k] * (uc - u);
+                M2[3 * k] = 0.0; M2[3 * k + 1] = as[k] * fv; M2[3 * k + 2] = as[k] * (vc - v);
+            }
+        }
+    }
+    __syncthreads();
+    // M^T M (upper computed, mirrored) and V = I, one element per lane-step
+    for (int idx = lane; idx < 144; idx += 64) {
+        const int a = idx / 12, b = idx - a * 12;
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        double acc = 0;
+        for (int r = 0; r < 2 * n; r++) acc += sh.M[r * 12 + lo] * sh.M[r * 12 + hi];
+        sh.A[idx] = acc;
+        sh.V[idx] = (a == b) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // parallel-order (round-robin) Jacobi: 6 disjoint rotations per round
+    for (int sweep = 0; sweep < 30; sweep++) {
+        if (lane == 0) sh.rotated = 0;
+        __syncthreads();
+        for (int r = 0; r < 11; r++) {
+            if (lane < 6) {
+                const int g = lane;
+                int a, b;
+                if (g == 0) { a = 11; b = r; }
+                else { a = (r + g) % 11; b = (r - g + 11) % 11; }
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                sh.P[g] = p; sh.Q[g] = q;
+                const double apq = sh.A[p * 12 + q], app = sh.A[p * 12 + p], aqq = sh.A[q * 12 + q];
+                if (apq == 0.0 || fabs(apq) <= 1e-18 * (fabs(app) + fabs(aqq))) { sh.C[g] = 1.0; sh.S[g] = 0.0; }
+                else {
+                    const double theta = (aqq - app) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0);
+                    sh.C[g] = c;
+                    sh.S[g] = t * c;
+                    atomicAdd(&sh.rotated, 1);
+                }
+            }
+            __syncthreads();
+            for (int idx = lane; idx < 72; idx += 64) {   // B = A J and V = V J, item = (row i, pair g)
+                const int i = idx / 6, g = idx - i * 6;
+                const int p = sh.P[g], q = sh.Q[g];
+                const double c = sh.C[g], s = sh.S[g];
+                double x = sh.A[i * 12 + p], y = sh.A[i * 12 + q];
+                sh.B[i * 12 + p] = c * x - s * y;
+                sh.B[i * 12 + q] = s * x + c * y;
+                x = sh.V[i * 12 + p]; y = sh.V[i * 12 + q];
+                sh.V[i * 12 + p] = c * x - s * y;
+                sh.V[i * 12 + q] = s * x + c * y;
+            }
+            __syncthreads();
+            for (int idx = lane; idx < 72; idx += 64) {   // A = J^T B, item = (column j, pair g)
+                const int j = idx / 6, g = idx - j * 6;
+                const int p = sh.P[g], q = sh.Q[g];
+                const double c = sh.C[g], s = sh.S[g];
+                const double x = sh.B[p * 12 + j], y = sh.B[q * 12 + j];
+                sh.A[p * 12 + j] = c * x - s * y;
+                sh.A[q * 12 + j] = s * x + c * y;
+            }
+            __syncthreads();
+        }
+        if (!sh.rotated) break;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        // ascending selection sort on the diagonal, keep the 4 smallest eigenvectors
+        double w[12];
+        int ord[12];
+        for (int i = 0; i < 12; i++) { w[i] = sh.A[i * 12 + i]; ord[i] = i; }
+        for (int i = 0; i < 11; i++) {
+            int m = i;
+            for (int j = i + 1; j < 12; j++) if (w[j] < w[m]) m = j;
+            if (m != i) { double t = w[i]; w[i] = w[m]; w[m] = t; int o = ord[i]; ord[i] = ord[m]; ord[m] = o; }
+        }
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 12; k++) sh.v4[i * 12 + k] = sh.V[k * 12 + ord[i]];
+        // compute_L_6x10, compute_rho
+        double L[60], rho[6];
+        {
+            double dv[4][6][3];
+            for (int i = 0; i < 4; i++) {
+                const double* v = sh.v4 + 12 * i;
+                int a = 0, b = 1;
+                for (int j = 0; j < 6; j++) {
+                    dv[i][j][0] = v[3 * a] - v[3 * b];
+                    dv[i][j][1] = v[3 * a + 1] - v[3 * b + 1];
+                    dv[i][j][2] = v[3 * a + 2] - v[3 * b + 2];
+                    b++;
+                    if (b > 3) { a++; b = a + 1; }
+                }
+            }
+            for (int i = 0; i < 6; i++) {
+                double* row = L + 10 * i;
+                row[0] = d_dot3(dv[0][i], dv[0][i]);
+                row[1] = 2.0f * d_dot3(dv[0][i], dv[1][i]);
+                row[2] = d_dot3(dv[1][i], dv[1][i]);
+                row[3] = 2.0f * d_dot3(dv[0][i], dv[2][i]);
+                row[4] = 2.0f * d_dot3(dv[1][i], dv[2][i]);
+                row[5] = d_dot3(dv[2][i], dv[2][i]);
+                row[6] = 2.0f * d_dot3(dv[0][i], dv[3][i]);
+                row[7] = 2.0f * d_dot3(dv[1][i], dv[3][i]);
+                row[8] = 2.0f * d_dot3(dv[2][i], dv[3][i]);
+                row[9] = d_dot3(dv[3][i], dv[3][i]);
+            }
+            const double* cws = sh.cws;
+            rho[0] = d_dist2(cws, cws + 3); rho[1] = d_dist2(cws, cws + 6); rho[2] = d_dist2(cws, cws + 9);
+            rho[3] = d_dist2(cws + 3, cws + 6); rho[4] = d_dist2(cws + 3, cws + 9); rho[5] = d_dist2(cws + 6, cws + 9);
+        }
+        double betas[4], bestR[9], bestt[3], best_err = 0;
+        for (int N = 1; N <= 3; N++) {
+            if (N == 1) {
+                double l4[24], b4[4];
+                for (int i = 0; i < 6; i++) { l4[i * 4] = L[i * 10]; l4[i * 4 + 1] = L[i * 10 + 1]; l4[i * 4 + 2] = L[i * 10 + 3]; l4[i * 4 + 3] = L[i * 10 + 6]; }
+                d_pinv_solve(l4, 6, 4, rho, b4);
+                if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
+                else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
+            } else if (N == 2) {
+                double l3[18], b3[3];
+                for (int i = 0; i < 6; i++) { l3[i * 3] = L[i * 10]; l3[i * 3 + 1] = L[i * 10 + 1]; l3[i * 3 + 2] = L[i * 10 + 2]; }
+                d_pinv_solve(l3, 6, 3, rho, b3);
+                if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
+                else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
+                if (b3[1] < 0) betas[0] = -betas[0];
+                betas[2] = 0.0; betas[3] = 0.0;
+            } else {
+                double l5[30], b5[5];
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 5; j++) l5[i * 5 + j] = L[i * 10 + j];
+                d_pinv_solve(l5, 6, 5, rho, b5);
+                if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+                else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+                if (b5[1] < 0) betas[0] = -betas[0];
+                betas[2] = b5[3] / betas[0];
+                betas[3] = 0.0;
+            }
+            epnp_gauss_newton(L, rho, betas);
+            double R[9], t[3];
+            const double e = epnp_R_and_t(sh, betas, fu, fv, uc, vc, R, t);
+            // N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3;
+            if (N == 1 || e < best_err) {
+                best_err = e;
+                for (int i = 0; i < 9; i++) bestR[i] = R[i];
+                for (int i = 0; i < 3; i++) bestt[i] = t[i];
+            }
+        }
+        double rv[3];
+        d_rodrigues_m2v(bestR, rv);
+        for (int i = 0; i < 3; i++) { models[h * 6 + i] = rv[i]; models[h * 6 + 3 + i] = bestt[i]; }
+    }
+}
+
+// grid = n_hyp, block = 256: float32 squared reprojection error of every point under hypothesis h (PnPRansacCallback::computeError)
+__global__ __launch_bounds__(256) void k_pnp_score(const float* __restrict__ obj, const float* __restrict__ img, int m,
+                                                   const double* __restrict__ K, const double* __restrict__ models,
+                                                   float thr, uint8_t* __restrict__ masks, int* __restrict__ counts) {
+    __shared__ double R[9];
+    __shared__ int wc[4];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) d_rodrigues_v2m(models + h * 6, R);
+    __syncthreads();
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double t0 = models[h * 6 + 3], t1 = models[h * 6 + 4], t2 = models[h * 6 + 5];
+    int good = 0;
+    for (int i = tid; i < m; i += 256) {
+        const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + t0;
+        double y = R[3] * X + R[4] * Y + R[5] * Z + t1;
+        double z = R[6] * X + R[7] * Y + R[8] * Z + t2;
+        z = z ? 1. / z : 1;
+        x *= z; y *= z;
+        const float px = (float)(x * fx + cx), py = (float)(y * fy + cy);
+        const float dx = img[2 * i] - px, dy = img[2 * i + 1] - py;
+        const float e = dx * dx + dy * dy;
+        const int f = e <= thr;
+        masks[(size_t)h * m + i] = (uint8_t)f;
+        good += f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) good += __shfl_xor(good, o, 64);
+    if ((tid & 63) == 0) wc[tid >> 6] = good;
+    __syncthreads();
+    if (tid == 0) counts[h] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+// ---- RANSAC bookkeeping + LM refit (one 256-thread workgroup) -----------------------------------------------------------
+__device__ inline int d_ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = fmax(p, 0.); p = fmin(p, 1.);
+    ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
+}
+
+__device__ inline void d_angle_axis_rotate_jac(const double a[3], const double q[3], double p[3], double dpdw[9]) {
+    const double theta2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    if (theta2 > DBL_EPSILON) {
+        const double theta = sqrt(theta2);
+        const double ct = cos(theta), st = sin(theta), ti = 1.0 / theta;
+        const double w[3] = {a[0] * ti, a[1] * ti, a[2] * ti};
+        const double wxq[3] = {w[1] * q[2] - w[2] * q[1], w[2] * q[0] - w[0] * q[2], w[0] * q[1] - w[1] * q[0]};
+        const double wq = w[0] * q[0] + w[1] * q[1] + w[2] * q[2];
+        const double tmp = wq * (1.0 - ct);
+        for (int i = 0; i < 3; i++) p[i] = q[i] * ct + wxq[i] * st + w[i] * tmp;
+        if (!dpdw) return;
+        for (int k = 0; k < 3; k++) {
+            double dwk[3];
+            for (int i = 0; i < 3; i++) dwk[i] = ((i == k ? 1.0 : 0.0) - w[i] * w[k]) * ti;
+            const double dwxq[3] = {dwk[1] * q[2] - dwk[2] * q[1], dwk[2] * q[0] - dwk[0] * q[2], dwk[0] * q[1] - dwk[1] * q[0]};
+            const double dwq = dwk[0] * q[0] + dwk[1] * q[1] + dwk[2] * q[2];
+            const double dct = -st * w[k], dst = ct * w[k];
+            const double dtmp = dwq * (1.0 - ct) + wq * (st * w[k]);
+            for (int i = 0; i < 3; i++) dpdw[i * 3 + k] = q[i] * dct + dwxq[i] * st + wxq[i] * dst + dwk[i] * tmp + w[i] * dtmp;
+        }
+    } else {
+        const double wxq[3] = {a[1] * q[2] - a[2] * q[1], a[2] * q[0] - a[0] * q[2], a[0] * q[1] - a[1] * q[0]};
+        for (int i = 0; i < 3; i++) p[i] = q[i] + wxq[i];
+        if (!dpdw) return;
+        dpdw[0] = 0;     dpdw[1] = q[2];  dpdw[2] = -q[1];
+        dpdw[3] = -q[2]; dpdw[4] = 0;     dpdw[5] = q[0];
+        dpdw[6] = q[1];  dpdw[7] = -q[0]; dpdw[8] = 0;
+    }
+}
+
+constexpr int RF_T = 256;
+struct RefitShared {
+    double red[4 * 28];
+    double JtJ[36], JtErr[6], param[6], prev[6];
+    double err2, prevErr2;
+    int best, last, n_in, state, lambdaLg10, iters, done;
+    int wsum[4];
+};
+
+// sums 28 values over the block (fixed tree), result valid in thread 0..27 of sh.red[0..27]
+__device__ inline void block_sum28(double* acc, RefitShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 28; k++) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[k] = v;
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 28; k++) sh.red[wid * 28 + k] = acc[k];
+    }
+    __syncthreads();
+    if (tid < 28) sh.red[tid] = sh.red[tid] + sh.red[28 + tid] + sh.red[56 + tid] + sh.red[84 + tid];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restrict__ obj, const float* __restrict__ img, int m,
+                                                           const double* __restrict__ K, const double* __restrict__ models,
+                                                           const uint8_t* __restrict__ masks, const int* __restrict__ counts,
+                                                           int n_hyp, double confidence, double* __restrict__ rt_out,
+                                                           int* __restrict__ inliers, int* __restrict__ info) {
+    __shared__ RefitShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) {
+        // RANSACPointSetRegistrator::run replayed over the precomputed hypotheses
+        int maxGood = 0, niters = n_hyp > 1 ? n_hyp : 1, best = -1, last = -1;
+        for (int iter = 0; iter < niters && iter < n_hyp; iter++) {
+            last = iter;
+            const int good = counts[iter];
+            if (good > (maxGood > 4 ? maxGood : 4)) {
+                best = iter;
+                maxGood = good;
+                niters = d_ransac_update_num_iters(confidence, (double)(m - good) / m, 5, niters);
+            }
+        }
+        sh.best = best; sh.last = last; sh.n_in = 0;
+        info[1] = last + 1;   // hypotheses the sequential algorithm would have evaluated
+    }
+    __syncthreads();
+    if (sh.best < 0) {
+        if (tid == 0) {
+            info[0] = 0;
+            const int l = sh.last < 0 ? 0 : sh.last;
+            for (int i = 0; i < 6; i++) rt_out[i] = models[l * 6 + i];
+        }
+        return;
+    }
+    // ordered compaction of the best mask
+    const uint8_t* mk = masks + (size_t)sh.best * m;
+    int base = 0;
+    for (int c0 = 0; c0 < m; c0 += RF_T) {
+        const int i = c0 + tid;
+        const int f = (i < m) ? mk[i] : 0;
+        const unsigned long long bal = __ballot(f);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) sh.wsum[wid] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wid; w++) off += sh.wsum[w];
+        if (f) inliers[off + before] = i;
+        const int tot = sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3];
+        __syncthreads();
+        base += tot;
+    }
+    const int n = base;
+    if (tid == 0) { sh.n_in = n; info[0] = n; }
+    // ---- cvFindExtrinsicCameraParams2 (useExtrinsicGuess): CvLevMarq state machine, initial guess = last evaluated model
+    if (tid < 6) { sh.param[tid] = models[sh.last * 6 + tid]; }
+    if (tid == 0) { sh.lambdaLg10 = -3; sh.iters = 0; sh.done = 0; sh.state = 0; }
+    __syncthreads();
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    // state 0: compute J & err at param, step; state 1: check err at new param
+    for (;;) {
+        const bool jac = (sh.state == 0);
+        double acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0;
+        const double p0 = sh.param[0], p1 = sh.param[1], p2 = sh.param[2], p3 = sh.param[3], p4 = sh.param[4], p5 = sh.param[5];
+        const double pa[3] = {p0, p1, p2};
+        for (int e = tid; e < n; e += RF_T) {
+            const int i = inliers[e];
+            const double X[3] = {(double)obj[3 * i], (double)obj[3 * i + 1], (double)obj[3 * i + 2]};
+            double Xc[3], dpdw[9];
+            d_angle_axis_rotate_jac(pa, X, Xc, jac ? dpdw : nullptr);
+            Xc[0] += p3; Xc[1] += p4; Xc[2] += p5;
+            const double z = Xc[2] ? 1. / Xc[2] : 1;
+            const double x = Xc[0] * z, y = Xc[1] * z;
+            const double ex = x * fx + cx - (double)img[2 * i], ey = y * fy + cy - (double)img[2 * i + 1];
+            acc[27] += ex * ex + ey * ey;
+            if (jac) {
+                double Ju[6], Jv[6];
+                const double du[3] = {fx * z, 0, -fx * x * z}, dv[3] = {0, fy * z, -fy * y * z};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    Ju[k] = du[0] * dpdw[k] + du[1] * dpdw[3 + k] + du[2] * dpdw[6 + k];
+                    Jv[k] = dv[0] * dpdw[k] + dv[1] * dpdw[3 + k] + dv[2] * dpdw[6 + k];
+                    Ju[3 + k] = du[k];
+                    Jv[3 + k] = dv[k];
+                }
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int b = a; b < 6; b++) acc[k++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                }
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[21 + a] += Ju[a] * ex + Jv[a] * ey;
+            }
+        }
+        block_sum28(acc, sh);
+        if (tid == 0) {
+            const double err2 = sh.red[27];
+            bool do_step = false;
+            if (sh.state == 0) {
+                int k = 0;
+                for (int a = 0; a < 6; a++)
+                    for (int b = a; b < 6; b++) { sh.JtJ[a * 6 + b] = sh.JtJ[b * 6 + a] = sh.red[k]; k++; }
+                for (int a = 0; a < 6; a++) { sh.JtErr[a] = sh.red[21 + a]; sh.prev[a] = sh.param[a]; }
+                if (sh.iters == 0) sh.prevErr2 = err2;
+                do_step = true;
+                sh.state = 1;
+            } else {
+                bool retry = false;
+                if (err2 > sh.prevErr2) {
+                    if (++sh.lambdaLg10 <= 16) { do_step = true; retry = true; }
+                }
+                if (!retry) {
+                    sh.lambdaLg10 = sh.lambdaLg10 - 1 > -16 ? sh.lambdaLg10 - 1 : -16;
+                    double dn = 0, pn = 0;
+                    for (int i = 0; i < 6; i++) { dn += (sh.param[i] - sh.prev[i]) * (sh.param[i] - sh.prev[i]); pn += sh.prev[i] * sh.prev[i]; }
+                    if (++sh.iters >= 20 || sqrt(dn) / sqrt(pn) < (double)FLT_EPSILON) sh.done = 1;
+                    else { sh.prevErr2 = err2; sh.state = 0; }
+                }
+            }
+            if (do_step) {
+                const double lambda = exp(sh.lambdaLg10 * log(10.));
+                double Am[36], b[6];
+                for (int i = 0; i < 36; i++) Am[i] = sh.JtJ[i];
+                for (int i = 0; i < 6; i++) { b[i] = sh.JtErr[i]; Am[i * 6 + i] *= 1. + lambda; }
+                bool ok = true;
+                for (int c = 0; c < 6 && ok; c++) {   // Gaussian elimination with partial pivoting
+                    int piv = c;
+                    for (int r = c + 1; r < 6; r++) if (fabs(Am[r * 6 + c]) > fabs(Am[piv * 6 + c])) piv = r;
+                    if (Am[piv * 6 + c] == 0.0) { ok = false; break; }
+                    if (piv != c) {
+                        for (int k = 0; k < 6; k++) { const double t = Am[c * 6 + k]; Am[c * 6 + k] = Am[piv * 6 + k]; Am[piv * 6 + k] = t; }
+                        const double t = b[c]; b[c] = b[piv]; b[piv] = t;
+                    }
+                    for (int r = c + 1; r < 6; r++) {
+                        const double f = Am[r * 6 + c] / Am[c * 6 + c];
+                        if (f == 0.0) continue;
+                        for (int k = c; k < 6; k++) Am[r * 6 + k] -= f * Am[c * 6 + k];
+                        b[r] -= f * b[c];
+                    }
+                }
+                if (ok) {
+                    for (int r = 5; r >= 0; r--) {
+                        double v = b[r];
+                        for (int k = r + 1; k < 6; k++) v -= Am[r * 6 + k] * b[k];
+                        b[r] = v / Am[r * 6 + r];
+                    }
+                } else for (int i = 0; i < 6; i++) b[i] = 0;
+                for (int i = 0; i < 6; i++) sh.param[i] = sh.prev[i] - b[i];
+            }
+        }
+        __syncthreads();
+        if (sh.done) break;
+    }
+    if (tid < 6) rt_out[tid] = sh.param[tid];
+}
+
+hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
+                      int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
+                      double* d_rt_out, int* d_inliers, int* d_info) {
+    hipLaunchKernelGGL(k_pnp_hyp, dim3(n_hyp), dim3(64), 0, s, d_obj, d_img, d_samples, d_K, d_models);
+    hipLaunchKernelGGL(k_pnp_score, dim3(n_hyp), dim3(256), 0, s, d_obj, d_img, m, d_K, d_models, thr, d_masks, d_counts);
+    hipLaunchKernelGGL(k_pnp_select_refit, dim3(1), dim3(RF_T), 0, s, d_obj, d_img, m, d_K, d_models, d_masks, d_counts, n_hyp,
+                       confidence, d_rt_out, d_inliers, d_info);
+    return hipGetLastError();
+}
+
+}  // namespace pmv

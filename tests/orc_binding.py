@@ -136,3 +136,66 @@ def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, b
     res = PipelineResult(lib, "orc_pipeline_", hnd)
     lib.orc_pipeline_free(hnd)
     return res
+
+
+def _ext(o):
+    lib = o.lib
+    return lib
+
+
+def ba_residuals(cams, pts, obs, cam_idx, pt_idx, K):
+    lib = load().lib
+    cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 6)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
+    ci = np.ascontiguousarray(cam_idx, np.int32)
+    pi = np.ascontiguousarray(pt_idx, np.int32)
+    Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+    n = obs.shape[0]
+    r = np.zeros((n, 2))
+    J = np.zeros((n, 2, 9))
+    lib.orc_ba_residuals(_p(cams, _f64p), cams.shape[0], _p(pts, _f64p), pts.shape[0], _p(obs, _f64p), _p(ci, _i32p),
+                         _p(pi, _i32p), n, _p(Kd, _f64p), _p(r, _f64p), _p(J, _f64p))
+    return r, J
+
+
+def ba_solve(cams, pts, obs, cam_idx, pt_idx, K, huber=1.0, max_iterations=5):
+    lib = load().lib
+    cams = np.array(cams, np.float64).reshape(-1, 6).copy()
+    pts = np.array(pts, np.float64).reshape(-1, 3).copy()
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
+    ci = np.ascontiguousarray(cam_idx, np.int32)
+    pi = np.ascontiguousarray(pt_idx, np.int32)
+    Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+    s = np.zeros(5)
+    lib.orc_ba_solve(_p(cams, _f64p), cams.shape[0], _p(pts, _f64p), pts.shape[0], _p(obs, _f64p), _p(ci, _i32p),
+                     _p(pi, _i32p), obs.shape[0], _p(Kd, _f64p), C.c_double(huber), max_iterations, _p(s, _f64p))
+    return cams, pts, dict(initial_cost=s[0], final_cost=s[1], iterations=int(s[2]), successful_steps=int(s[3]),
+                           termination=int(s[4]))
+
+
+def pnp_ransac(obj, img, K, rvec, tvec, iterations=100, reproj_err=8.0, confidence=0.99):
+    lib = load().lib
+    o = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    i2 = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    m = o.shape[0]
+    Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+    rv = np.array(rvec, np.float64).reshape(3).copy()
+    tv = np.array(tvec, np.float64).reshape(3).copy()
+    inl = np.zeros(max(m, 1), np.int32)
+    hu = C.c_int()
+    n = lib.orc_pnp_ransac(_p(o, _f32p), _p(i2, _f32p), m, _p(Kd, _f64p), _p(rv, _f64p), _p(tv, _f64p), iterations,
+                           C.c_float(reproj_err), C.c_double(confidence), _p(inl, _i32p), C.byref(hu))
+    return rv, tv, inl[:max(n, 0)].copy(), hu.value
+
+
+def rodrigues_v2m(r):
+    R = np.zeros(9)
+    load().lib.orc_rodrigues_v2m(_p(np.ascontiguousarray(r, np.float64), _f64p), _p(R, _f64p))
+    return R.reshape(3, 3)
+
+
+def rodrigues_m2v(R):
+    r = np.zeros(3)
+    load().lib.orc_rodrigues_m2v(_p(np.ascontiguousarray(R, np.float64).reshape(9), _f64p), _p(r, _f64p))
+    return r
