@@ -89,6 +89,9 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
                    double* tvec, int iterations, float reproj_err, double confidence, int* out_inliers,
                    int* out_n_inliers);
 
+/* Debug/parity: models (n*6: rvec,tvec) and inlier counts of the first n hypotheses of the last pmv_pnp_ransac call. */
+int pmv_debug_pnp_hypotheses(pmv_ctx* ctx, int n, double* models, int* counts);
+
 /* ---- bundle adjustment ------------------------------------------------------------------------------------- */
 typedef struct pmv_ba_summary {
     double initial_cost, final_cost;
@@ -106,6 +109,32 @@ int pmv_ba_residuals(pmv_ctx* ctx, const double* cams, int nc, const double* pts
 int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
                  const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations,
                  pmv_ba_summary* summary);
+
+/* ---- whole-sequence driver -------------------------------------------------------------------------------------- */
+/* Runs the reference's OdometryPipeline schedule (initialise, addFrame per frame, estimatePose with lag 2, BA every
+ * bundle_size/3*2 frames; OdometryPipeline.cpp:247-264, :329-426) with every plugin call served by the kernels above.
+ * Frames 0..n_frames-1 must already be staged in slots 0..n_frames-1 (pmv_frames_stage); with build_pyramids != 0 the
+ * pyramids of all frames are (re)built first, inside the call, so that a benchmark times HBM-resident gray frames ->
+ * poses. gt_poses12: n_frames KITTI pose rows (only the translation column is used, for the monocular scale, quirk Q11). */
+typedef struct pmv_pipeline_params {
+    int n_frames, w, h;
+    int min_tracked_features, tracked_features_tol, init_frames, bundle_size, ba_iterations;
+    int extractor;      /* 0 = goodFeaturesToTrack (reference default), 1 = ShiTomasi */
+    int threaded;       /* 0 = sequential schedule, 1 = front-end / back-end host threads (the reference's two threads) */
+    int n_threads;      /* unused by the HIP path */
+    int build_pyramids; /* rebuild the pyramids of slots 0..n_frames-1 inside the call */
+} pmv_pipeline_params;
+typedef struct pmv_pipeline_result pmv_pipeline_result;
+
+int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* params, const double* K9, const double* gt_poses12,
+                     pmv_pipeline_result** out);
+void pmv_pipeline_free(pmv_pipeline_result* r);
+int pmv_pipeline_num_poses(const pmv_pipeline_result* r);
+void pmv_pipeline_get_poses(const pmv_pipeline_result* r, double* out12); /* per pose: R row-major (9) then t (3) */
+int pmv_pipeline_num_frames(const pmv_pipeline_result* r);
+int pmv_pipeline_frame_feature_count(const pmv_pipeline_result* r, int k);
+void pmv_pipeline_get_frame_features(const pmv_pipeline_result* r, int k, int* out3); /* (column,row,landmark id|-1) */
+void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out16);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ struct CpuPnP : EPnPSolverBase {
     bool pnp_ransac(const float* obj, const float* img, int m, const double* K, double* rvec, double* tvec,
                     std::vector<int>& inliers) override {
         inliers.assign(std::max(m, 1), 0);
+        if (m < 6) { inliers.clear(); return false; }   // same guard as the product ABI (the reference never gets here: m >= tol)
         const int n = orc::pnp_ransac(obj, img, m, K, rvec, tvec, 100, 8.f, .99, inliers.data(), nullptr);
         inliers.resize(n > 0 ? n : 0);
         return n > 0;

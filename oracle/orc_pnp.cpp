@@ -338,7 +338,7 @@ struct EPnP {
 };
 
 // PnPRansacCallback::computeError: float32 squared reprojection distance
-static void reproj_errors(const double rvec[3], const double tvec[3], const double K[9], const float* obj, const float* img,
+void reproj_errors(const double rvec[3], const double tvec[3], const double K[9], const float* obj, const float* img,
                           int m, float* err) {
     double R[9];
     rodrigues_v2m(rvec, R);
@@ -512,6 +512,33 @@ void orc_epnp(const float* obj, const float* img, int n, const double* K, double
 int orc_pnp_ransac(const float* obj, const float* img, int m, const double* K, double* rvec, double* tvec, int iters,
                    float reproj_err, double confidence, int* inliers, int* hyp_used) {
     return orc::pnp_ransac(obj, img, m, K, rvec, tvec, iters, reproj_err, confidence, inliers, hyp_used);
+}
+// debug/parity: all `iters` hypotheses without the adaptive cut-off: models (iters x 6), inlier counts
+void orc_pnp_hypotheses(const float* obj, const float* img, int m, const double* K, int iters, float reproj_err, double* models, int* counts) {
+    orc::RNG rng((uint64_t)-1);
+    std::vector<float> err(m);
+    const float thr = (float)((double)reproj_err * (double)reproj_err);
+    for (int it = 0; it < iters; it++) {
+        int idx[5];
+        for (int i = 0; i < 5;) {
+            int idx_i;
+            for (;;) {
+                idx_i = idx[i] = rng.uniform(0, m);
+                int j = 0;
+                for (; j < i; j++) if (idx_i == idx[j]) break;
+                if (j == i) break;
+            }
+            i++;
+        }
+        orc::EPnP e(K, obj, img, idx, 5);
+        double R[9];
+        e.compute_pose(R, models + it * 6 + 3);
+        orc::rodrigues_m2v(R, models + it * 6);
+        orc::reproj_errors(models + it * 6, models + it * 6 + 3, K, obj, img, m, err.data());
+        int good = 0;
+        for (int i = 0; i < m; i++) good += err[i] <= thr;
+        counts[it] = good;
+    }
 }
 void orc_rng_sequence(uint64_t seed, int n, int bound, int* out) {
     orc::RNG r(seed);

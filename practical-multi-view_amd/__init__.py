@@ -36,8 +36,43 @@ ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
     "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frame_get_level", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
-    "pmv_lk_track", "pmv_pnp_ransac", "pmv_ba_residuals", "pmv_ba_solve",
+    "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_ba_residuals", "pmv_ba_solve",
+    "pmv_pipeline_run", "pmv_pipeline_free", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
+    "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_get_stats",
 ]
+
+
+class PipelineParams(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("w", C.c_int), ("h", C.c_int), ("min_tracked_features", C.c_int),
+                ("tracked_features_tol", C.c_int), ("init_frames", C.c_int), ("bundle_size", C.c_int),
+                ("ba_iterations", C.c_int), ("extractor", C.c_int), ("threaded", C.c_int), ("n_threads", C.c_int),
+                ("build_pyramids", C.c_int)]
+
+
+STAT_KEYS = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
+             "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale"]
+
+
+class PipelineResult:
+    """poses (n,12: R row-major then t), per-frame (column,row,landmark) triples in container order, run statistics"""
+
+    def __init__(self, lib, handle, want_features=True):
+        n = lib.pmv_pipeline_num_poses(handle)
+        self.poses = np.zeros((n, 12), np.float64)
+        if n:
+            lib.pmv_pipeline_get_poses(handle, _p(self.poses, _f64p))
+        self.features = []
+        if want_features:
+            for k in range(lib.pmv_pipeline_num_frames(handle)):
+                c = lib.pmv_pipeline_frame_feature_count(handle, k)
+                a = np.zeros((c, 3), np.int32)
+                if c:
+                    lib.pmv_pipeline_get_frame_features(handle, k, _p(a, _i32p))
+                self.features.append(a)
+        st = np.zeros(16, np.float64)
+        lib.pmv_pipeline_get_stats(handle, _p(st, _f64p))
+        self.stats = dict(zip(STAT_KEYS, [float(v) for v in st[:len(STAT_KEYS)]]))
+
 
 _lib = None
 _synth = None
@@ -57,6 +92,15 @@ def load_library():
         _lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
         _lib.pmv_last_error.restype = C.c_char_p
         _lib.pmv_last_error.argtypes = [C.c_void_p]
+        if hasattr(_lib, "pmv_pipeline_run"):
+            _lib.pmv_pipeline_run.argtypes = [C.c_void_p, C.POINTER(PipelineParams), _f64p, _f64p, C.POINTER(C.c_void_p)]
+            _lib.pmv_pipeline_free.argtypes = [C.c_void_p]
+            _lib.pmv_pipeline_num_poses.argtypes = [C.c_void_p]
+            _lib.pmv_pipeline_get_poses.argtypes = [C.c_void_p, _f64p]
+            _lib.pmv_pipeline_num_frames.argtypes = [C.c_void_p]
+            _lib.pmv_pipeline_frame_feature_count.argtypes = [C.c_void_p, C.c_int]
+            _lib.pmv_pipeline_get_frame_features.argtypes = [C.c_void_p, C.c_int, _i32p]
+            _lib.pmv_pipeline_get_stats.argtypes = [C.c_void_p, _f64p]
     return _lib
 
 
@@ -201,6 +245,12 @@ class Context:
                                          _p(inl, _i32p), C.byref(nin)))
         return rv, tv, inl[: nin.value].copy()
 
+    def pnp_hypotheses(self, n=100):
+        models = np.zeros((n, 6), np.float64)
+        counts = np.zeros(n, np.int32)
+        self._ck(self.lib.pmv_debug_pnp_hypotheses(self.h, n, _p(models, _f64p), _p(counts, _i32p)))
+        return models, counts
+
     # ---- BaseOptimizer role ----
     def ba_residuals(self, cams, pts, obs_xy, cam_idx, pt_idx, K):
         cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 6)
@@ -229,3 +279,18 @@ class Context:
                                        _p(obs, _f64p), _p(ci, _i32p), _p(pi, _i32p), obs.shape[0], _p(Kd, _f64p),
                                        C.c_double(huber), max_iterations, C.byref(s)))
         return cams, pts, s
+
+    # ---- whole sequence (OdometryPipeline role) ----
+    def pipeline_run(self, n_frames, w, h, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5,
+                     ba_iterations=5, extractor=0, threaded=0, build_pyramids=1, want_features=True):
+        """frames 0..n_frames-1 must be staged in slots 0..n_frames-1 (frames_stage)"""
+        P = PipelineParams(n_frames, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
+                           0, build_pyramids)
+        Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+        gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n_frames, 12)
+        out = C.c_void_p()
+        self._ck(self.lib.pmv_pipeline_run(self.h, C.byref(P), _p(Kd, _f64p), _p(gt, _f64p), C.byref(out)))
+        try:
+            return PipelineResult(self.lib, out, want_features)
+        finally:
+            self.lib.pmv_pipeline_free(out)

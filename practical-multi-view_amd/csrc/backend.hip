@@ -2,6 +2,8 @@
 #include "pmv_ctx.h"
 #include "backend.h"
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 
@@ -104,6 +106,12 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     REQ(iterations >= 1 && iterations <= MAX_HYP, PMV_ERR_CAPACITY, "pmv_pnp_ransac: iterations=%d (1..%d)", iterations, MAX_HYP);
     REQ(confidence > 0 && confidence < 1, PMV_ERR_INVALID, "pmv_pnp_ransac: confidence must be in (0,1)");
     CKC(hipSetDevice(ctx->device));
+    if (const char* dump = getenv("PMV_DUMP_PNP")) {   // debug: append the inputs of every call to a file
+        if (FILE* f = fopen(dump, "ab")) {
+            fwrite(&m, 4, 1, f); fwrite(obj_xyz, 12, m, f); fwrite(img_xy, 8, m, f); fwrite(K, 8, 9, f); fwrite(rvec, 8, 3, f); fwrite(tvec, 8, 3, f);
+            fclose(f);
+        }
+    }
     BackendBuffers* b = ctx->be;
     hipStream_t s = ctx->s_back;
     char* hs = (char*)b->h_stage;
@@ -144,6 +152,16 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     for (int i = 0; i < 3; i++) { rvec[i] = h_rt[i]; tvec[i] = h_rt[3 + i]; }
     *out_n_inliers = n;
     if (n > 0) memcpy(out_inliers, h_inl, (size_t)n * 4);
+    return PMV_OK;
+}
+
+// debug/parity: models (n x 6) and inlier counts of the hypotheses evaluated by the last pmv_pnp_ransac call
+int pmv_debug_pnp_hypotheses(pmv_ctx* ctx, int n, double* models, int* counts) {
+    REQ(ctx && models && counts && n >= 1 && n <= MAX_HYP, PMV_ERR_INVALID, "pmv_debug_pnp_hypotheses: bad argument");
+    CKC(hipSetDevice(ctx->device));
+    CKC(hipStreamSynchronize(ctx->s_back));
+    CKC(hipMemcpy(models, ctx->be->d_models, (size_t)n * 48, hipMemcpyDeviceToHost));
+    CKC(hipMemcpy(counts, ctx->be->d_counts, (size_t)n * 4, hipMemcpyDeviceToHost));
     return PMV_OK;
 }
 

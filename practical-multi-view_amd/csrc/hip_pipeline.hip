@@ -1,0 +1,136 @@
+// HIP plugin set: the reference's five plugin roles served through the C ABI of this library, plugged into the host
+// pipeline mirror (host/vo_pipeline.*). This is the drop-in: OdometryPipeline/addFrame/estimatePose stay host C++,
+// every numerically heavy call crosses into the gfx950 kernels. No CPU fallback exists on this path (the triangulator,
+// which the north star does not move to the device, is the host implementation in host/vo_fivepoint.cpp).
+#include "pmv_ctx.h"
+#include "vo_capi_impl.h"
+#include <cstring>
+#include <stdexcept>
+
+namespace {
+using namespace vo;
+
+struct HipError : std::runtime_error { int code; HipError(int c, const char* m) : std::runtime_error(m), code(c) {} };
+inline void ck(pmv_ctx* ctx, int rc) { if (rc != PMV_OK) throw HipError(rc, pmv_last_error(ctx)); }
+
+static void cells_of(const std::vector<ImageView>& cells, std::vector<int>& out) {
+    out.clear();
+    for (auto& c : cells) { out.push_back(c.x0); out.push_back(c.y0); out.push_back(c.w); out.push_back(c.h); }
+}
+
+struct HipGftt : GoodFeatureExtractorBase {
+    pmv_ctx* ctx;
+    std::vector<int> rect, xy, cnt;
+    void gftt(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out) override {
+        out.assign(cells.size(), {});
+        if (cells.empty() || max < 1) return;
+        cells_of(cells, rect);
+        xy.resize(cells.size() * (size_t)max * 2);
+        cnt.resize(cells.size());
+        ck(ctx, pmv_detect_gftt(ctx, cells[0].slot, rect.data(), (int)cells.size(), max, quality, min_distance, xy.data(), cnt.data()));
+        for (size_t c = 0; c < cells.size(); c++)
+            for (int i = 0; i < cnt[c]; i++) out[c].push_back({xy[(c * max + i) * 2], xy[(c * max + i) * 2 + 1]});
+    }
+};
+struct HipShiTomasi : ShiTomasiExtractorBase {
+    pmv_ctx* ctx;
+    std::vector<int> rect, xy, cnt;
+    std::vector<double> sc;
+    void shitomasi(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out,
+                   std::vector<std::vector<double>>& score) override {
+        out.assign(cells.size(), {});
+        score.assign(cells.size(), {});
+        if (cells.empty() || max < 1) return;
+        cells_of(cells, rect);
+        xy.resize(cells.size() * (size_t)max * 2);
+        sc.resize(cells.size() * (size_t)max);
+        cnt.resize(cells.size());
+        ck(ctx, pmv_detect_shitomasi(ctx, cells[0].slot, rect.data(), (int)cells.size(), max, quality, xy.data(), sc.data(), cnt.data()));
+        for (size_t c = 0; c < cells.size(); c++)
+            for (int i = 0; i < cnt[c]; i++) {
+                out[c].push_back({xy[(c * max + i) * 2], xy[(c * max + i) * 2 + 1]});
+                score[c].push_back(sc[c * max + i]);
+            }
+    }
+};
+struct HipLK : LucasKanadeFMBase {
+    pmv_ctx* ctx;
+    void pyrlk(const ImageView& prev, const ImageView& next, const float* prev_xy, int n, float* next_xy, uint8_t* status,
+               float* err) override {
+        ck(ctx, pmv_lk_track(ctx, prev.slot, next.slot, prev_xy, n, next_xy, status, err));
+    }
+};
+struct HipPnP : EPnPSolverBase {
+    pmv_ctx* ctx;
+    bool pnp_ransac(const float* obj, const float* img, int m, const double* K, double* rvec, double* tvec,
+                    std::vector<int>& inliers) override {
+        inliers.assign(m > 0 ? m : 1, 0);
+        int n = 0;
+        const int rc = pmv_pnp_ransac(ctx, obj, img, m, K, rvec, tvec, 100, 8.f, .99, inliers.data(), &n);
+        if (rc == PMV_ERR_DEGENERATE) { inliers.clear(); return false; }   // cv::Exception in the reference
+        ck(ctx, rc);
+        inliers.resize(n);
+        return n > 0;
+    }
+};
+struct HipBA : BundleAdjustmentBase {
+    pmv_ctx* ctx;
+    void ba_solve(double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx, const int* pt_idx, int n_obs,
+                  const double* K, double huber, int max_iterations) override {
+        ck(ctx, pmv_ba_solve(ctx, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, nullptr));
+    }
+};
+}  // namespace
+
+struct pmv_pipeline_result { vo::PipelineRun run; };
+
+extern "C" {
+
+int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K9, const double* gt_poses12,
+                     pmv_pipeline_result** out) {
+    if (!ctx || !P || !K9 || !gt_poses12 || !out) { pmv::set_err(ctx, "pmv_pipeline_run: null argument"); return PMV_ERR_INVALID; }
+    if (P->n_frames < P->init_frames + 2 || P->n_frames > ctx->n_slots || P->init_frames < 1) {
+        pmv::set_err(ctx, "pmv_pipeline_run: n_frames=%d (slots %d, init_frames %d)", P->n_frames, ctx->n_slots, P->init_frames);
+        return PMV_ERR_CAPACITY;
+    }
+    if (P->bundle_size != 0 && P->bundle_size < 3) { pmv::set_err(ctx, "pmv_pipeline_run: bundle_size 1..2 divides by zero in the reference (OdometryPipeline.cpp:407)"); return PMV_ERR_INVALID; }
+    if (P->bundle_size > ctx->max_ba_cams) { pmv::set_err(ctx, "pmv_pipeline_run: bundle_size exceeds max_ba_cams"); return PMV_ERR_CAPACITY; }
+    auto* res = new pmv_pipeline_result();
+    vo::PipelineRun& run = res->run;
+    vo::PipelineParams vp;
+    memcpy(&vp, P, sizeof(vp));   // identical leading layout; the last int is build_pyramids here
+    try {
+        if (P->build_pyramids) ck(ctx, pmv_frames_build(ctx, 0, P->n_frames));
+        vo::pipeline_setup(run, vp, nullptr, K9, gt_poses12);
+        vo::BaseFeatureExtractor* ex;
+        if (P->extractor == 1) { auto* e = new HipShiTomasi(); e->ctx = ctx; ex = e; }
+        else { auto* e = new HipGftt(); e->ctx = ctx; ex = e; }
+        run.owned_ex.push_back(ex);
+        auto* lk = new HipLK(); lk->ctx = ctx;
+        auto* pnp = new HipPnP(); pnp->ctx = ctx; pnp->tracker = &run.pipe;
+        auto* tri = new vo::FivePointTri(); tri->tracker = &run.pipe;
+        auto* ba = new HipBA(); ba->ctx = ctx; ba->tracker = &run.pipe;
+        run.m = lk; run.p = pnp; run.tr = tri; run.b = ba;
+        run.pipe.extractor = ex; run.pipe.matcher = lk; run.pipe.pnpsolver = pnp; run.pipe.triangulator = tri; run.pipe.ba = ba;
+        vo::pipeline_execute(run, vp);
+    } catch (const HipError& e) {
+        pmv::set_err(ctx, "pmv_pipeline_run: %s", e.what());
+        const int code = e.code;
+        delete res;
+        return code;
+    } catch (const std::exception& e) {
+        pmv::set_err(ctx, "pmv_pipeline_run: %s", e.what());
+        delete res;
+        return PMV_ERR_INVALID;
+    }
+    *out = res;
+    return PMV_OK;
+}
+void pmv_pipeline_free(pmv_pipeline_result* r) { delete r; }
+int pmv_pipeline_num_poses(const pmv_pipeline_result* r) { return vo::pipeline_num_poses(r->run); }
+void pmv_pipeline_get_poses(const pmv_pipeline_result* r, double* out) { vo::pipeline_get_poses(r->run, out); }
+int pmv_pipeline_num_frames(const pmv_pipeline_result* r) { return vo::pipeline_num_frames(r->run); }
+int pmv_pipeline_frame_feature_count(const pmv_pipeline_result* r, int k) { return vo::pipeline_frame_feature_count(r->run, k); }
+void pmv_pipeline_get_frame_features(const pmv_pipeline_result* r, int k, int* out) { vo::pipeline_get_frame_features(r->run, k, out); }
+void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out16) { vo::pipeline_get_stats(r->run, out16); }
+}
