@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""VO frames/s of the MI355X hot path on the BASELINE metric config (synthetic KITTI-like 1241x376 mono sequence,
+1101 frames, 400 tracked features (tol 150), bundle_size 5, 5 LM iterations).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the whole pipeline over one sequence whose gray frames are already resident in HBM: pyramid
+build for every frame, per-frame LK / re-detection, lag-2 PnP | triangulation, BA every 2nd frame, poses back on host.
+Sequences are independent, so with N GPUs every rank runs its own sequence (weak scaling, no data-path collective);
+the only collective is the final RCCL all-gather of the pose arrays. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[1] (metric config). Real KITTI seq 07 frames are 1226x370; the metric quotes 1241x376.
+WORKLOAD = dict(w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, n_frames=1101, min_tracked=400, tol=150,
+                init_frames=5, bundle_size=5, ba_iterations=5)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=WORKLOAD["n_frames"], help="frames per sequence (default: metric config)")
+    ap.add_argument("--cpu-frames", type=int, default=150, help="bounded sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--sequential", action="store_true", help="one host thread instead of front-end/back-end threads")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        # torch first: it brings its own libamdhip64 and the product library must bind to the same HIP runtime
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pmv = importlib.import_module("practical-multi-view_amd")
+    if not os.path.exists(pmv.lib_path()):
+        importlib.import_module("practical-multi-view_amd.build").build_all()
+    import numpy as np
+
+    wl = dict(WORKLOAD)
+    wl["n_frames"] = args.frames
+    n, w, h = wl["n_frames"], wl["w"], wl["h"]
+    seed = 1000 + 7 + rank   # "KITTI 07"-like on rank 0; every rank gets its own sequence
+    ncpu = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.time()
+    frames, gt = pmv.synth_sequence(seed, 0, n, w, h, wl["fx"], wl["fy"], wl["cx"], wl["cy"], nthreads=ncpu)
+    t_gen = time.time() - t0
+    K = np.array([wl["fx"], 0, wl["cx"], 0, wl["fy"], wl["cy"], 0, 0, 1.0])
+
+    ctx = pmv.Context(w, h, n_slots=n, max_tracks=4096, max_ba_cams=32, max_ba_points=8192, max_ba_obs=65536, device=local_rank)
+    ctx.frames_stage(0, frames)   # inputs resident in HBM before the timed region
+
+    def step():
+        return ctx.pipeline_run(n, w, h, K, gt, min_tracked=wl["min_tracked"], tol=wl["tol"], init_frames=wl["init_frames"],
+                                bundle_size=wl["bundle_size"], ba_iterations=wl["ba_iterations"], threaded=0 if args.sequential else 1,
+                                build_pyramids=1, want_features=False)
+
+    def sync_all():
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    ctx.prof_enable(True)
+    sync_all()
+    t0 = time.perf_counter()
+    gathered = None
+    for _ in range(args.steps):
+        res = step()
+        if dist is not None:   # final pose concatenation over RCCL/xGMI (latency-bound: <= 106 KB per rank)
+            buf = torch.zeros((n, 12), dtype=torch.float64, device="cuda")
+            buf[: res.poses.shape[0]] = torch.from_numpy(res.poses).cuda()
+            gathered = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(gathered, buf)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    prof = ctx.prof_read()
+
+    if rank != 0:
+        ctx.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    frames_per_step = (n - int(res.stats["init_offset"])) * world   # frames that went through addFrame + estimatePose per step
+    value = frames_per_step * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (HIP events on its own stream, averaged over the timed region) ---------------
+    levels = []
+    lw, lh = w, h
+    for _ in range(5):
+        levels.append((lw, lh))
+        lw, lh = (lw + 1) // 2, (lh + 1) // 2
+        if lw <= 32 or lh <= 32:
+            break
+    pyr_px = sum(a * b for a, b in levels)
+    st = res.stats
+    per_launch_bytes = {
+        # both pyramids read once + 13 B per track out
+        "k_lk": 2.0 * pyr_px + 13.0 * (st["lk_points"] / max(st["lk_calls"], 1)),
+        # obj (12 B) + img (8 B) per point in, model out; hypotheses re-read them from L2
+        "k_pnp_hyp": 20.0 * (st["pnp_points"] / max(st["pnp_calls"], 1)) + 100 * 48.0,
+        "k_pnp_score": 20.0 * (st["pnp_points"] / max(st["pnp_calls"], 1)) + 100 * (st["pnp_points"] / max(st["pnp_calls"], 1)),
+        "k_pnp_select_refit": 20.0 * (st["pnp_points"] / max(st["pnp_calls"], 1)),
+        # B_ba = n_obs*(2+2+4+4)*8 B per LM iteration (Jacobians recomputed, not stored)
+        "k_ba_lm": 96.0 * (st["ba_obs"] / max(st["ba_calls"], 1)) * wl["ba_iterations"],
+        "k_gftt_eig": float(w * h), "k_gftt_select": 4.0 * w * h,
+        "k_pad_level0": (w * h + (w + 128) * (h + 128)) * float(n), "k_pyrdown": 0.0,
+    }
+    kern = {k: dict(launches=v[0], total_ms=round(v[1], 4), avg_us=round(v[1] / v[0] * 1e3, 3), max_us=round(v[2] * 1e3, 3)) for k, v in prof.items()}
+    dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
+    roofline = None
+    if dom:
+        avg_s = prof[dom][1] / prof[dom][0] * 1e-3
+        achieved = per_launch_bytes.get(dom, 0.0) / avg_s / 1e9
+        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 4), peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
+                        traffic=None, avg_launch_us=round(avg_s * 1e6, 3), algorithmic_bytes_per_launch=round(per_launch_bytes.get(dom, 0.0), 1))
+
+    # ---- CPU baseline: the oracle pipeline (CPU restatement of the reference) on a bounded prefix of the same workload ----
+    cpu = None
+    if args.cpu_frames > 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc_binding as ob
+        nthr = args.cpu_threads or max(1, ncpu - 1)
+        m = min(args.cpu_frames, n)
+        t0 = time.perf_counter()
+        o = ob.run_pipeline(frames[:m], K, gt[:m], min_tracked=wl["min_tracked"], tol=wl["tol"], init_frames=wl["init_frames"],
+                            bundle_size=wl["bundle_size"], ba_iterations=wl["ba_iterations"], threaded=1, n_threads=nthr)
+        dt = time.perf_counter() - t0
+        cpu = dict(value=round((m - int(o.stats["init_offset"])) / dt, 3), unit="frames/s", cores=nthr + 1, kind="port",
+                   sample=f"first {m} frames of the same sequence; oracle pipeline, front-end + back-end threads, LK over {nthr} worker threads",
+                   seconds=round(dt, 3))
+
+    # trajectory sanity vs synthetic ground truth (z flipped: the pipeline's forward axis is -z, quirk Q14)
+    off = int(st["init_offset"])
+    est = res.poses[:, 9:12]
+    g = gt[off: off + len(est), [3, 7, 11]] - gt[off, [3, 7, 11]]
+    g = g * np.array([1, 1, -1])
+    terr = np.linalg.norm(est - g, axis=1)
+
+    out = {
+        "metric": "VO frames/sec on 1241x376 KITTI mono @400 tracks, bundle=5",
+        "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/int32 front-end, f64 back-end", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: synthetic KITTI-07-like sequence {w}x{h}, {n} frames, 400 tracks (tol 150), "
+                               f"bundle_size 5, 5 LM iterations, init_frames 5, GFTT+LK+EPnP-RANSAC+BA; one sequence per GPU",
+                   "frames_per_step": frames_per_step, "host_threads": 1 if args.sequential else 2},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "kernels": kern,
+        "pipeline_stats": {k: st[k] for k in ("lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls",
+                                              "ba_obs", "ba_points", "heuristic_motion", "n_landmarks")},
+        "host_stage_seconds_per_step": {k: round(st[k], 4) for k in ("t_lk", "t_detect", "t_pnp", "t_tri", "t_ba", "t_pnp_kernel", "t_ba_kernel")},
+        "trajectory_error_m": {"mean": round(float(terr.mean()), 3), "max": round(float(terr.max()), 3),
+                               "travelled": round(float(np.linalg.norm(g[-1])), 1)},
+        "input_generation_s": round(t_gen, 2),
+    }
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
+    print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

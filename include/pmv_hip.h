@@ -110,6 +110,12 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
                  const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations,
                  pmv_ba_summary* summary);
 
+/* ---- per-kernel timing (HIP events on the launching stream; used by bench.py for the roofline object) -------------- */
+int pmv_prof_enable(pmv_ctx* ctx, int on);  /* on != 0: reset counters and start recording; 0: stop */
+int pmv_prof_kernel_count(void);
+const char* pmv_prof_kernel_name(int id);
+int pmv_prof_read(pmv_ctx* ctx, int id, int* launches, double* total_ms, double* max_ms);
+
 /* ---- whole-sequence driver -------------------------------------------------------------------------------------- */
 /* Runs the reference's OdometryPipeline schedule (initialise, addFrame per frame, estimatePose with lag 2, BA every
  * bundle_size/3*2 frames; OdometryPipeline.cpp:247-264, :329-426) with every plugin call served by the kernels above.

@@ -17,6 +17,10 @@ namespace orc {
 inline void jacobi_eig(double* A, int n, double* w, double* V, int max_sweeps = 30) {
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    // off-diagonals below 1e-17 * trace are noise (they would only rotate rounding errors inside null spaces for ever)
+    double tol_abs = 0;
+    for (int i = 0; i < n; i++) tol_abs += std::fabs(A[i * n + i]);
+    tol_abs *= 1e-17;
     for (int sweep = 0; sweep < max_sweeps; sweep++) {
         int rotated = 0;
         for (int p = 0; p < n - 1; p++)
@@ -24,8 +28,7 @@ inline void jacobi_eig(double* A, int n, double* w, double* V, int max_sweeps = 
                 const double apq = A[p * n + q];
                 if (apq == 0.0) continue;
                 const double app = A[p * n + p], aqq = A[q * n + q];
-                // skip rotations that cannot change the diagonal in double precision
-                if (std::fabs(apq) <= 1e-18 * (std::fabs(app) + std::fabs(aqq)) ) { A[p * n + q] = A[q * n + p] = 0.0; continue; }
+                if (std::fabs(apq) <= tol_abs) { A[p * n + q] = A[q * n + p] = 0.0; continue; }
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
                 const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
@@ -73,6 +76,9 @@ inline void jacobi_eig_parallel(double* A, int n, double* w, double* V, int max_
     std::vector<double> B((size_t)n * n);
     std::vector<int> P(n / 2), Q(n / 2);
     std::vector<double> C(n / 2), S(n / 2);
+    double tol_abs = 0;
+    for (int i = 0; i < n; i++) tol_abs += std::fabs(A[i * n + i]);
+    tol_abs *= 1e-17;
     for (int sweep = 0; sweep < max_sweeps; sweep++) {
         int rotated = 0;
         for (int r = 0; r < n - 1; r++) {
@@ -83,7 +89,8 @@ inline void jacobi_eig_parallel(double* A, int n, double* w, double* V, int max_
                 const int p = a < b ? a : b, q = a < b ? b : a;
                 P[g] = p; Q[g] = q;
                 const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
-                if (apq == 0.0 || std::fabs(apq) <= 1e-18 * (std::fabs(app) + std::fabs(aqq))) { C[g] = 1.0; S[g] = 0.0; continue; }
+                if (std::fabs(apq) <= tol_abs) { C[g] = 1.0; S[g] = 0.0; continue; }
+                (void)app;
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
                 C[g] = 1.0 / std::sqrt(t * t + 1.0);
@@ -310,10 +317,11 @@ inline void cholesky_solve(const double* L, int n, double* b) {
         for (int k = 0; k < i; k++) v -= L[i * n + k] * b[k];
         b[i] = v / L[i * n + i];
     }
+    // backward substitution, column-oriented (row k receives its updates in DESCENDING i): the order a lane-per-row
+    // wavefront evaluates
     for (int i = n - 1; i >= 0; i--) {
-        double v = b[i];
-        for (int k = i + 1; k < n; k++) v -= L[k * n + i] * b[k];
-        b[i] = v / L[i * n + i];
+        b[i] = b[i] / L[i * n + i];
+        for (int k = 0; k < i; k++) b[k] -= L[i * n + k] * b[i];
     }
 }
 

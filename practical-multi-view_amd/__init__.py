@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frame_get_level", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_ba_residuals", "pmv_ba_solve",
+    "pmv_prof_enable", "pmv_prof_kernel_count", "pmv_prof_kernel_name", "pmv_prof_read",
     "pmv_pipeline_run", "pmv_pipeline_free", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
     "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_get_stats",
 ]
@@ -50,7 +51,8 @@ class PipelineParams(C.Structure):
 
 
 STAT_KEYS = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
-             "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale"]
+             "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale", "t_lk", "t_detect", "t_pnp", "t_tri",
+             "t_ba", "t_pnp_kernel", "t_ba_kernel"]
 
 
 class PipelineResult:
@@ -69,7 +71,7 @@ class PipelineResult:
                 if c:
                     lib.pmv_pipeline_get_frame_features(handle, k, _p(a, _i32p))
                 self.features.append(a)
-        st = np.zeros(16, np.float64)
+        st = np.zeros(24, np.float64)
         lib.pmv_pipeline_get_stats(handle, _p(st, _f64p))
         self.stats = dict(zip(STAT_KEYS, [float(v) for v in st[:len(STAT_KEYS)]]))
 
@@ -279,6 +281,21 @@ class Context:
                                        _p(obs, _f64p), _p(ci, _i32p), _p(pi, _i32p), obs.shape[0], _p(Kd, _f64p),
                                        C.c_double(huber), max_iterations, C.byref(s)))
         return cams, pts, s
+
+    # ---- per-kernel HIP-event timing ----
+    def prof_enable(self, on=True):
+        self._ck(self.lib.pmv_prof_enable(self.h, 1 if on else 0))
+
+    def prof_read(self):
+        """{kernel: (launches, total_ms, max_ms)} for every kernel class launched since prof_enable(True)"""
+        self.lib.pmv_prof_kernel_name.restype = C.c_char_p
+        out = {}
+        for i in range(self.lib.pmv_prof_kernel_count()):
+            n, tot, mx = C.c_int(), C.c_double(), C.c_double()
+            self._ck(self.lib.pmv_prof_read(self.h, i, C.byref(n), C.byref(tot), C.byref(mx)))
+            if n.value:
+                out[self.lib.pmv_prof_kernel_name(i).decode()] = (n.value, tot.value, mx.value)
+        return out
 
     # ---- whole sequence (OdometryPipeline role) ----
     def pipeline_run(self, n_frames, w, h, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5,

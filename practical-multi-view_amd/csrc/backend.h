@@ -14,6 +14,7 @@ struct BAArgs {
     // workspaces (device)
     double *x, *cand, *scale, *diag, *D2, *step, *res, *J, *Einv, *gp, *Yd, *Wd, *S, *rhs, *Gpart, *summary;
     int ldw, krows, tiles_r, tiles_c, kslices, kper, gp_rows;
+    unsigned long long* stamps;   // optional (diagnostic): 32 accumulated shader-clock phase timers
 };
 
 hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,

@@ -20,9 +20,15 @@ struct BackendBuffers {
            *d_J = nullptr, *d_Einv = nullptr, *d_gp = nullptr, *d_Yd = nullptr, *d_Wd = nullptr, *d_S = nullptr, *d_rhs = nullptr,
            *d_Gpart = nullptr, *d_summary = nullptr;
     size_t ydwd_elems = 0, gpart_elems = 0;
-    // pinned staging
+    unsigned long long* d_stamps = nullptr;
+    // single-copy transfers: one pinned staging block and one device block per direction
     void* h_stage = nullptr;
     size_t h_stage_bytes = 0;
+    char* d_ba_io = nullptr;   // [summary 8 | cams | pts | obs | K | cam_idx | pt_idx | pobs_start | pobs_list | cobs_start | cobs_list]
+    size_t ba_io_bytes = 0;
+    char* d_pnp_in = nullptr;  // [K 10 doubles | obj | img | samples]
+    char* d_pnp_out = nullptr; // [rt 6 doubles | info 4 ints | inliers]
+    size_t pnp_in_bytes = 0, pnp_out_bytes = 0;
     // PnP
     float *d_obj = nullptr, *d_img = nullptr;
     int *d_samples = nullptr, *d_counts = nullptr, *d_inliers = nullptr, *d_info = nullptr;
@@ -53,6 +59,8 @@ int backend_create(pmv_ctx* c) {
     b->gpart_elems = (size_t)8 * ldw * ldw;   // up to 8 K-slices of an (ldw x ldw) tile grid
     CKB(hipMalloc(&b->d_Gpart, b->gpart_elems * 8));
     CKB(hipMalloc(&b->d_summary, 8 * 8));
+    CKB(hipMalloc(&b->d_stamps, 32 * 8));
+    CKB(hipMemset(b->d_stamps, 0, 32 * 8));
     const size_t mt = (size_t)c->max_tracks;
     b->h_stage_bytes = std::max<size_t>(no * 18 * 8 + no * 2 * 8, std::max<size_t>(n * 8 + no * 32 + (np + nc + 2) * 4, mt * 32 + MAX_HYP * 20 + 4096));
     CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes));
@@ -61,6 +69,15 @@ int backend_create(pmv_ctx* c) {
     CKB(hipMalloc(&b->d_inliers, mt * 4)); CKB(hipMalloc(&b->d_info, 16));
     CKB(hipMalloc(&b->d_models, MAX_HYP * 6 * 8)); CKB(hipMalloc(&b->d_rt, 6 * 8)); CKB(hipMalloc(&b->d_Kp, 9 * 8));
     CKB(hipMalloc(&b->d_masks, (size_t)MAX_HYP * mt));
+    b->ba_io_bytes = (8 + nc * 6 + np * 3 + no * 2 + 10) * 8 + (no * 4 + np + nc + 8) * 4 + 64;
+    CKB(hipMalloc(&b->d_ba_io, b->ba_io_bytes));
+    b->pnp_in_bytes = 80 + mt * 20 + (size_t)MAX_HYP * 20 + 64;
+    b->pnp_out_bytes = 48 + 16 + mt * 4 + 64;
+    CKB(hipMalloc(&b->d_pnp_in, b->pnp_in_bytes));
+    CKB(hipMalloc(&b->d_pnp_out, b->pnp_out_bytes));
+    b->h_stage_bytes = std::max(b->h_stage_bytes, std::max(b->ba_io_bytes, b->pnp_in_bytes + b->pnp_out_bytes));
+    (void)hipHostFree(b->h_stage);
+    CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes));
 #undef CKB
     return PMV_OK;
 }
@@ -71,7 +88,7 @@ void backend_destroy(pmv_ctx* c) {
     void* ptrs[] = {b->d_cams, b->d_pts, b->d_obs, b->d_K, b->d_cam_idx, b->d_pt_idx, b->d_pobs_start, b->d_pobs_list, b->d_cobs_start,
                     b->d_cobs_list, b->d_x, b->d_cand, b->d_scale, b->d_diag, b->d_D2, b->d_step, b->d_res, b->d_J, b->d_Einv, b->d_gp,
                     b->d_Yd, b->d_Wd, b->d_S, b->d_rhs, b->d_Gpart, b->d_summary, b->d_obj, b->d_img, b->d_samples, b->d_counts,
-                    b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks};
+                    b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     delete b;
@@ -105,6 +122,7 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     REQ(m >= 6, PMV_ERR_DEGENERATE, "pmv_pnp_ransac: %d correspondences (need >= 6)", m);
     REQ(iterations >= 1 && iterations <= MAX_HYP, PMV_ERR_CAPACITY, "pmv_pnp_ransac: iterations=%d (1..%d)", iterations, MAX_HYP);
     REQ(confidence > 0 && confidence < 1, PMV_ERR_INVALID, "pmv_pnp_ransac: confidence must be in (0,1)");
+    tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     if (const char* dump = getenv("PMV_DUMP_PNP")) {   // debug: append the inputs of every call to a file
         if (FILE* f = fopen(dump, "ab")) {
@@ -115,11 +133,15 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     BackendBuffers* b = ctx->be;
     hipStream_t s = ctx->s_back;
     char* hs = (char*)b->h_stage;
-    float* h_obj = (float*)hs; float* h_img = (float*)(hs + (size_t)m * 12); int* h_samples = (int*)(hs + (size_t)m * 20);
-    double* h_K = (double*)(hs + (size_t)m * 20 + (size_t)iterations * 20 + 8 - (((size_t)m * 20 + (size_t)iterations * 20) % 8));
+    // one pinned block: [K 10 doubles | obj 3m floats | img 2m floats | samples 5*iterations ints]
+    double* h_K = (double*)hs;
+    float* h_obj = (float*)(hs + 80);
+    float* h_img = h_obj + (size_t)3 * m;
+    int* h_samples = (int*)(h_img + (size_t)2 * m);
+    const size_t in_bytes = 80 + (size_t)m * 20 + (size_t)iterations * 20;
+    memcpy(h_K, K, 72);
     memcpy(h_obj, obj_xyz, (size_t)m * 12);
     memcpy(h_img, img_xy, (size_t)m * 8);
-    memcpy(h_K, K, 72);
     CvRNG rng((uint64_t)-1);
     for (int it = 0; it < iterations; it++) {
         int* idx = h_samples + it * 5;
@@ -134,24 +156,36 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
             i++;
         }
     }
-    CKC(hipMemcpyAsync(b->d_obj, h_obj, (size_t)m * 12, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_img, h_img, (size_t)m * 8, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_samples, h_samples, (size_t)iterations * 20, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_Kp, h_K, 72, hipMemcpyHostToDevice, s));
+    CKC(hipMemcpyAsync(b->d_pnp_in, hs, in_bytes, hipMemcpyHostToDevice, s));
+    const double* d_K = (const double*)b->d_pnp_in;
+    const float* d_obj = (const float*)(b->d_pnp_in + 80);
+    const float* d_img = d_obj + (size_t)3 * m;
+    const int* d_samples = (const int*)(d_img + (size_t)2 * m);
+    double* d_rt = (double*)b->d_pnp_out;
+    int* d_info = (int*)(b->d_pnp_out + 48);
+    int* d_inl = (int*)(b->d_pnp_out + 64);
     const float thr = (float)((double)reproj_err * (double)reproj_err);
-    CKC(launch_pnp(s, b->d_obj, b->d_img, m, b->d_Kp, b->d_samples, iterations, thr, confidence, b->d_models, b->d_masks, b->d_counts,
-                   b->d_rt, b->d_inliers, b->d_info));
-    double* h_rt = (double*)hs;                      // staging reused for the results
-    int* h_info = (int*)(hs + 64);
-    int* h_inl = (int*)(hs + 128);
-    CKC(hipMemcpyAsync(h_rt, b->d_rt, 48, hipMemcpyDeviceToHost, s));
-    CKC(hipMemcpyAsync(h_info, b->d_info, 8, hipMemcpyDeviceToHost, s));
-    CKC(hipMemcpyAsync(h_inl, b->d_inliers, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    CKC(launch_pnp(s, d_obj, d_img, m, d_K, d_samples, iterations, thr, confidence, b->d_models, b->d_masks, b->d_counts,
+                   d_rt, d_inl, d_info));
+    char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
+    CKC(hipMemcpyAsync(ho, b->d_pnp_out, 64 + (size_t)m * 4, hipMemcpyDeviceToHost, s));
     CKC(hipStreamSynchronize(s));
+    const double* h_rt = (const double*)ho;
+    const int* h_info = (const int*)(ho + 48);
+    const int* h_inl = (const int*)(ho + 64);
     const int n = h_info[0];
     for (int i = 0; i < 3; i++) { rvec[i] = h_rt[i]; tvec[i] = h_rt[3 + i]; }
     *out_n_inliers = n;
     if (n > 0) memcpy(out_inliers, h_inl, (size_t)n * 4);
+    return PMV_OK;
+}
+
+// diagnostic: accumulated per-phase shader-clock counters of k_ba_lm (enabled by PMV_BA_STAMPS=1), 32 values
+int pmv_debug_ba_stamps(pmv_ctx* ctx, unsigned long long* out32) {
+    REQ(ctx && out32, PMV_ERR_INVALID, "null argument");
+    CKC(hipSetDevice(ctx->device));
+    CKC(hipStreamSynchronize(ctx->s_back));
+    CKC(hipMemcpy(out32, ctx->be->d_stamps, 256, hipMemcpyDeviceToHost));
     return PMV_OK;
 }
 
@@ -172,6 +206,7 @@ int pmv_ba_residuals(pmv_ctx* ctx, const double* cams, int nc, const double* pts
         "pmv_ba_residuals: nc=%d np=%d n_obs=%d exceed capacity %d/%d/%d", nc, np, n_obs, ctx->max_ba_cams, ctx->max_ba_points, ctx->max_ba_obs);
     for (int i = 0; i < n_obs; i++) REQ(cam_idx[i] >= 0 && cam_idx[i] < nc && pt_idx[i] >= 0 && pt_idx[i] < np, PMV_ERR_INVALID, "pmv_ba_residuals: index out of range at observation %d", i);
     if (n_obs == 0) return PMV_OK;
+    tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     BackendBuffers* b = ctx->be;
     hipStream_t s = ctx->s_back;
@@ -194,12 +229,24 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     REQ(nc >= 1 && nc <= ctx->max_ba_cams && np >= 1 && np <= ctx->max_ba_points && n_obs >= 1 && n_obs <= ctx->max_ba_obs, PMV_ERR_CAPACITY,
         "pmv_ba_solve: nc=%d np=%d n_obs=%d exceed capacity %d/%d/%d", nc, np, n_obs, ctx->max_ba_cams, ctx->max_ba_points, ctx->max_ba_obs);
     REQ(max_iterations >= 0 && huber_delta > 0, PMV_ERR_INVALID, "pmv_ba_solve: bad options");
+    tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     BackendBuffers* b = ctx->be;
     hipStream_t s = ctx->s_back;
-    // observation lists per point / per camera (counting sort, observation order preserved)
+    // one pinned block mirrors the device block: [summary 8 | cams | pts | obs | K 10 | cam_idx | pt_idx | pstart | plist | cstart | clist]
     char* hs = (char*)b->h_stage;
-    int* pstart = (int*)hs; int* plist = pstart + (np + 1); int* cstart = plist + n_obs; int* clist = cstart + (nc + 1);
+    double* h_sum = (double*)hs;
+    double* h_cams = h_sum + 8;
+    double* h_pts = h_cams + (size_t)nc * 6;
+    double* h_obs = h_pts + (size_t)np * 3;
+    double* h_K = h_obs + (size_t)n_obs * 2;
+    int* h_ci = (int*)(h_K + 10);
+    int* h_pi = h_ci + n_obs;
+    int* pstart = h_pi + n_obs; int* plist = pstart + (np + 1); int* cstart = plist + n_obs; int* clist = cstart + (nc + 1);
+    const size_t io_bytes = (size_t)((char*)(clist + n_obs) - hs);
+    memcpy(h_cams, cams, (size_t)nc * 48); memcpy(h_pts, pts, (size_t)np * 24); memcpy(h_obs, obs_xy, (size_t)n_obs * 16);
+    memcpy(h_K, K, 72); memcpy(h_ci, cam_idx, (size_t)n_obs * 4); memcpy(h_pi, pt_idx, (size_t)n_obs * 4);
+    // observation lists per point / per camera (counting sort, observation order preserved)
     std::fill(pstart, pstart + np + 1, 0);
     std::fill(cstart, cstart + nc + 1, 0);
     for (int i = 0; i < n_obs; i++) {
@@ -212,22 +259,24 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
         std::vector<int> pf(pstart, pstart + np), cf(cstart, cstart + nc);
         for (int i = 0; i < n_obs; i++) { plist[pf[pt_idx[i]]++] = i; clist[cf[cam_idx[i]]++] = i; }
     }
-    CKC(hipMemcpyAsync(b->d_pobs_start, pstart, (size_t)(np + 1) * 4, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_pobs_list, plist, (size_t)n_obs * 4, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_cobs_start, cstart, (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_cobs_list, clist, (size_t)n_obs * 4, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_cams, cams, (size_t)nc * 48, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_pts, pts, (size_t)np * 24, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_obs, obs_xy, (size_t)n_obs * 16, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_cam_idx, cam_idx, (size_t)n_obs * 4, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_pt_idx, pt_idx, (size_t)n_obs * 4, hipMemcpyHostToDevice, s));
-    CKC(hipMemcpyAsync(b->d_K, K, 72, hipMemcpyHostToDevice, s));
+    REQ(io_bytes <= b->ba_io_bytes, PMV_ERR_CAPACITY, "pmv_ba_solve: io block too small");
+    CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
+    char* dio = b->d_ba_io;
+    double* d_sum = (double*)dio;
+    double* d_cams = d_sum + 8;
+    double* d_pts = d_cams + (size_t)nc * 6;
+    double* d_obs = d_pts + (size_t)np * 3;
+    double* d_K = d_obs + (size_t)n_obs * 2;
+    int* d_ci = (int*)(d_K + 10);
+    int* d_pi = d_ci + n_obs;
+    int* d_pstart = d_pi + n_obs; int* d_plist = d_pstart + (np + 1); int* d_cstart = d_plist + n_obs; int* d_clist = d_cstart + (nc + 1);
     BAArgs A;
-    A.cams = b->d_cams; A.pts = b->d_pts; A.obs = b->d_obs; A.cam_idx = b->d_cam_idx; A.pt_idx = b->d_pt_idx; A.K = b->d_K;
-    A.pobs_start = b->d_pobs_start; A.pobs_list = b->d_pobs_list; A.cobs_start = b->d_cobs_start; A.cobs_list = b->d_cobs_list;
+    A.cams = d_cams; A.pts = d_pts; A.obs = d_obs; A.cam_idx = d_ci; A.pt_idx = d_pi; A.K = d_K;
+    A.pobs_start = d_pstart; A.pobs_list = d_plist; A.cobs_start = d_cstart; A.cobs_list = d_clist;
     A.nc = nc; A.np = np; A.nobs = n_obs; A.max_iterations = max_iterations; A.huber = huber_delta;
     A.x = b->d_x; A.cand = b->d_cand; A.scale = b->d_scale; A.diag = b->d_diag; A.D2 = b->d_D2; A.step = b->d_step; A.res = b->d_res; A.J = b->d_J;
-    A.Einv = b->d_Einv; A.gp = b->d_gp; A.Yd = b->d_Yd; A.Wd = b->d_Wd; A.S = b->d_S; A.rhs = b->d_rhs; A.Gpart = b->d_Gpart; A.summary = b->d_summary;
+    A.Einv = b->d_Einv; A.gp = b->d_gp; A.Yd = b->d_Yd; A.Wd = b->d_Wd; A.S = b->d_S; A.rhs = b->d_rhs; A.Gpart = b->d_Gpart; A.summary = d_sum;
+    A.stamps = getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr;
     const int m = 6 * nc;
     A.tiles_r = (m + 15) / 16; A.tiles_c = (m + 1 + 15) / 16;
     A.ldw = A.tiles_c * 16;
@@ -239,13 +288,12 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     A.kper = round_up((A.krows + ks - 1) / ks, 4);
     A.kslices = (A.krows + A.kper - 1) / A.kper;
     REQ((size_t)A.krows * A.ldw <= b->ydwd_elems && (size_t)A.kslices * A.gp_rows * A.ldw <= b->gpart_elems, PMV_ERR_CAPACITY, "pmv_ba_solve: workspace too small");
+    REQ(((size_t)m * m + 2 * (size_t)m + 27 * 128) * 8 <= 150 * 1024, PMV_ERR_CAPACITY, "pmv_ba_solve: %d cameras exceed the LDS-resident reduced system (max 20)", nc);
     CKC(launch_ba_lm(s, A));
-    double* h_out = (double*)hs;
-    CKC(hipStreamSynchronize(s));   // staging (pstart...) is reused below
-    CKC(hipMemcpyAsync(h_out, b->d_summary, 40, hipMemcpyDeviceToHost, s));
-    CKC(hipMemcpyAsync(h_out + 8, b->d_cams, (size_t)nc * 48, hipMemcpyDeviceToHost, s));
-    CKC(hipMemcpyAsync(h_out + 8 + (size_t)nc * 6, b->d_pts, (size_t)np * 24, hipMemcpyDeviceToHost, s));
+    const size_t out_bytes = (8 + (size_t)nc * 6 + (size_t)np * 3) * 8;
+    CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));
     CKC(hipStreamSynchronize(s));
+    const double* h_out = (const double*)hs;
     memcpy(cams, h_out + 8, (size_t)nc * 48);
     memcpy(pts, h_out + 8 + (size_t)nc * 6, (size_t)np * 24);
     if (summary) {

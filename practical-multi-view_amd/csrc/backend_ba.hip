@@ -10,6 +10,7 @@
 //   Cholesky of the reduced camera matrix -> back-substitution -> model cost change -> candidate cost -> accept/reject.
 #include "pmv_ctx.h"
 #include "backend.h"
+#include "pmv_prof.h"
 #include <float.h>
 
 namespace pmv {
@@ -18,6 +19,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int BA_T = 512;
 constexpr int BA_NW = BA_T / 64;
+constexpr int CB_CH = 128;   // camera-block chunk (observations per LDS tile)
 
 // ---- ceres::AngleAxisRotatePoint + exact derivatives (both branches) -------------------------------------------------
 __device__ inline void angle_axis_rotate(const double a[3], const double q[3], double p[3], double dpdw[9], double Rm[9], bool jac) {
@@ -59,6 +61,84 @@ __device__ inline void angle_axis_rotate(const double a[3], const double q[3], d
         Rm[0] = 1;     Rm[1] = -a[2]; Rm[2] = a[1];
         Rm[3] = a[2];  Rm[4] = 1;     Rm[5] = -a[0];
         Rm[6] = -a[1]; Rm[7] = a[0];  Rm[8] = 1;
+    }
+}
+
+// Per-camera constants of AngleAxisRotatePoint: theta-dependent terms are identical for every observation of a camera, so
+// they are evaluated once per camera and evaluation point (same expressions, same bits as evaluating them per observation).
+struct CamRot { double ct, st, ti, w0, w1, w2; int big; int pad; };
+__device__ inline void cam_rot_setup(const double a[3], CamRot& c) {
+    const double theta2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    if (theta2 > DBL_EPSILON) {
+        const double theta = sqrt(theta2);
+        c.ct = cos(theta); c.st = sin(theta); c.ti = 1.0 / theta;
+        c.w0 = a[0] * c.ti; c.w1 = a[1] * c.ti; c.w2 = a[2] * c.ti;
+        c.big = 1;
+    } else { c.ct = 1; c.st = 0; c.ti = 0; c.w0 = a[0]; c.w1 = a[1]; c.w2 = a[2]; c.big = 0; }
+}
+__device__ inline void angle_axis_rotate_pre(const CamRot& c, const double q[3], double p[3], double dpdw[9], double Rm[9], bool jac) {
+    if (c.big) {
+        const double ct = c.ct, st = c.st, ti = c.ti;
+        const double w[3] = {c.w0, c.w1, c.w2};
+        const double wxq[3] = {w[1] * q[2] - w[2] * q[1], w[2] * q[0] - w[0] * q[2], w[0] * q[1] - w[1] * q[0]};
+        const double wq = w[0] * q[0] + w[1] * q[1] + w[2] * q[2];
+        const double tmp = wq * (1.0 - ct);
+#pragma unroll
+        for (int i = 0; i < 3; i++) p[i] = q[i] * ct + wxq[i] * st + w[i] * tmp;
+        if (!jac) return;
+        const double c1 = 1.0 - ct;
+        Rm[0] = ct + c1 * w[0] * w[0];        Rm[1] = c1 * w[0] * w[1] - st * w[2]; Rm[2] = c1 * w[0] * w[2] + st * w[1];
+        Rm[3] = c1 * w[1] * w[0] + st * w[2]; Rm[4] = ct + c1 * w[1] * w[1];        Rm[5] = c1 * w[1] * w[2] - st * w[0];
+        Rm[6] = c1 * w[2] * w[0] - st * w[1]; Rm[7] = c1 * w[2] * w[1] + st * w[0]; Rm[8] = ct + c1 * w[2] * w[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double dwk[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) dwk[i] = ((i == k ? 1.0 : 0.0) - w[i] * w[k]) * ti;
+            const double dwxq[3] = {dwk[1] * q[2] - dwk[2] * q[1], dwk[2] * q[0] - dwk[0] * q[2], dwk[0] * q[1] - dwk[1] * q[0]};
+            const double dwq = dwk[0] * q[0] + dwk[1] * q[1] + dwk[2] * q[2];
+            const double dct = -st * w[k], dst = ct * w[k];
+            const double dtmp = dwq * (1.0 - ct) + wq * (st * w[k]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) dpdw[i * 3 + k] = q[i] * dct + dwxq[i] * st + wxq[i] * dst + dwk[i] * tmp + w[i] * dtmp;
+        }
+    } else {
+        const double a[3] = {c.w0, c.w1, c.w2};
+        const double wxq[3] = {a[1] * q[2] - a[2] * q[1], a[2] * q[0] - a[0] * q[2], a[0] * q[1] - a[1] * q[0]};
+#pragma unroll
+        for (int i = 0; i < 3; i++) p[i] = q[i] + wxq[i];
+        if (!jac) return;
+        dpdw[0] = 0;     dpdw[1] = q[2];  dpdw[2] = -q[1];
+        dpdw[3] = -q[2]; dpdw[4] = 0;     dpdw[5] = q[0];
+        dpdw[6] = q[1];  dpdw[7] = -q[0]; dpdw[8] = 0;
+        Rm[0] = 1;     Rm[1] = -a[2]; Rm[2] = a[1];
+        Rm[3] = a[2];  Rm[4] = 1;     Rm[5] = -a[0];
+        Rm[6] = -a[1]; Rm[7] = a[0];  Rm[8] = 1;
+    }
+}
+// same as projection_residual with the camera's rotation constants precomputed
+__device__ inline void projection_residual_pre(const CamRot& cr, const double* cam, const double* X, double ox, double oy, const double* K,
+                                               double r[2], double* Jc, double* Jp, bool jac) {
+    const double fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+    const double q[3] = {X[0] + cam[3], X[1] + cam[4], X[2] + cam[5]};
+    double p[3], dpdw[9], Rm[9];
+    angle_axis_rotate_pre(cr, q, p, dpdw, Rm, jac);
+    const double pz = p[2] * -1.0;
+    const double u = p[0] / pz * fx + cx, v = p[1] / pz * fy + cy;
+    r[0] = ox - u;
+    r[1] = oy - v;
+    if (!jac) return;
+    const double ipz = 1.0 / pz;
+    const double du[3] = {fx * ipz, 0.0, fx * p[0] * ipz * ipz};
+    const double dv[3] = {0.0, fy * ipz, fy * p[1] * ipz * ipz};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double ju_w = du[0] * dpdw[0 * 3 + k] + du[1] * dpdw[1 * 3 + k] + du[2] * dpdw[2 * 3 + k];
+        const double jv_w = dv[0] * dpdw[0 * 3 + k] + dv[1] * dpdw[1 * 3 + k] + dv[2] * dpdw[2 * 3 + k];
+        const double ju_q = du[0] * Rm[0 * 3 + k] + du[1] * Rm[1 * 3 + k] + du[2] * Rm[2 * 3 + k];
+        const double jv_q = dv[0] * Rm[0 * 3 + k] + dv[1] * Rm[1 * 3 + k] + dv[2] * Rm[2 * 3 + k];
+        Jc[k] = -ju_w; Jc[6 + k] = -jv_w; Jc[3 + k] = -ju_q; Jc[9 + k] = -jv_q;
+        Jp[k] = -ju_q; Jp[3 + k] = -jv_q;
     }
 }
 
@@ -149,10 +229,14 @@ __device__ inline void huber_rho(double s, double a, double& rho0, double& rho1)
     } else { rho0 = s; rho1 = 1; }
 }
 
+#define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
     __shared__ double red[BA_NW];
     __shared__ double cred[BA_NW * 27];
     __shared__ BAState st;
+    __shared__ CamRot crot[32];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];   // S (m*m) | rhs (m) | stepc (m): the reduced camera system
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nc = A.nc, np = A.np, nobs = A.nobs;
     const int n = 6 * nc + 3 * np, m = 6 * nc;
@@ -160,8 +244,13 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
     const int krows = A.krows;      // 3*np padded to a multiple of 4
     double* x = A.x; double* cand = A.cand; double* scale = A.scale; double* diag = A.diag; double* D2 = A.D2;
     double* step = A.step; double* res = A.res; double* J = A.J; double* Einv = A.Einv; double* gp = A.gp;
-    double* Yd = A.Yd; double* Wd = A.Wd; double* S = A.S; double* rhs = A.rhs; double* Gp = A.Gpart;
+    double* Yd = A.Yd; double* Wd = A.Wd; double* Gp = A.Gpart;
+    double* S = dyn; double* rhs = dyn + (size_t)m * m; double* stepc = rhs + m; double* ctile = stepc + m;   // ctile: 27 x CB_CH
 
+    // diagnostic phase timers (shader clock), only when A.stamps != nullptr
+    unsigned long long t_prev = 0;
+#define STAMP(k) do { if (A.stamps) { __syncthreads(); if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); A.stamps[k] += t_ - t_prev; t_prev = t_; } } } while (0)
+    if (A.stamps && tid == 0) { t_prev = __builtin_readcyclecounter(); A.stamps[30] = wall_clock64(); A.stamps[31] = t_prev; }
     // x <- [cams | pts]
     for (int i = tid; i < 6 * nc; i += BA_T) x[i] = A.cams[i];
     for (int i = tid; i < 3 * np; i += BA_T) x[6 * nc + i] = A.pts[i];
@@ -175,10 +264,12 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         // ================= (re-)evaluate cost, corrected residuals and Jacobians at x ======================================
         if (st.need_eval) {
             double cpart = 0;
+            if (tid < nc) cam_rot_setup(x + 6 * tid, crot[tid]);
+            __syncthreads();
             for (int i = tid; i < nobs; i += BA_T) {
                 double r[2], Jc[12], Jp[6];
                 const int c = A.cam_idx[i], p = A.pt_idx[i];
-                projection_residual(x + 6 * c, x + 6 * nc + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, Jc, Jp, true);
+                projection_residual_pre(crot[c], x + 6 * c, x + 6 * nc + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, Jc, Jp, true);
                 double rho0, rho1;
                 huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
                 cpart += 0.5 * rho0;
@@ -242,6 +333,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
             if (tid == 0) { st.need_eval = 0; st.first = 0; st.gmax = -1.0; }
             __syncthreads();
         }
+        STAMP(0);
         // ================= loop-top termination tests (FinalizeIterationAndCheckIfMinimizerCanContinue) ======================
         // (gmax is produced by the Schur phase below; on the first pass it is not known yet and is checked after that phase)
         if (tid == 0) {
@@ -255,44 +347,58 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         // ================= camera blocks: U_c = sum Jc^T Jc, rhs_c = sum Jc^T r (tree reductions) ===========================
         for (int i = tid; i < m * m; i += BA_T) S[i] = 0.0;
         __syncthreads();
+        // per camera, in chunks of CB_CH observations: every observation's 27 products (21 of Jc^T Jc, 6 of Jc^T r) go to an
+        // LDS tile [27][CB_CH]; 27 x 8 threads add 1/8 of a column each, then 27 threads add the 8 partials in order.
         for (int c = 0; c < nc; c++) {
-            double acc[27];
+            const int e0 = A.cobs_start[c], e1 = A.cobs_start[c + 1];
+            double tot = 0;   // running total of value `tid` (tid < 27) across the chunks of this camera
+            for (int cb = e0; cb < e1; cb += CB_CH) {
+                const int cnt = min(CB_CH, e1 - cb);
+                if (tid < cnt) {
+                    const int i = A.cobs_list[cb + tid];
+                    const double* Jc = J + (size_t)i * 18;
+                    double jc[12];
 #pragma unroll
-            for (int k = 0; k < 27; k++) acc[k] = 0;
-            for (int e = A.cobs_start[c] + tid; e < A.cobs_start[c + 1]; e += BA_T) {
-                const int i = A.cobs_list[e];
-                const double* Jc = J + (size_t)i * 18;
-                const double r0 = res[2 * i], r1 = res[2 * i + 1];
-                int k = 0;
+                    for (int k = 0; k < 12; k++) jc[k] = Jc[k];
+                    const double r0 = res[2 * i], r1 = res[2 * i + 1];
+                    int k = 0;
 #pragma unroll
-                for (int a = 0; a < 6; a++) {
+                    for (int a = 0; a < 6; a++) {
 #pragma unroll
-                    for (int b = a; b < 6; b++) acc[k++] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+                        for (int b = a; b < 6; b++) { ctile[k * CB_CH + tid] = jc[a] * jc[b] + jc[6 + a] * jc[6 + b]; k++; }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 6; a++) ctile[(21 + a) * CB_CH + tid] = jc[a] * r0 + jc[6 + a] * r1;
                 }
+                __syncthreads();
+                if (tid < 27 * 8) {
+                    const int k = tid >> 3, part = tid & 7;
+                    const int lo = part * (CB_CH / 8), hi = min(cnt, lo + CB_CH / 8);
+                    double sacc = 0;
+                    for (int j = lo; j < hi; j++) sacc += ctile[k * CB_CH + j];
+                    cred[k * 8 + part] = sacc;
+                }
+                __syncthreads();
+                if (tid < 27) {
+                    double sacc = cred[tid * 8];
 #pragma unroll
-                for (int a = 0; a < 6; a++) acc[21 + a] += Jc[a] * r0 + Jc[6 + a] * r1;
+                    for (int q = 1; q < 8; q++) sacc += cred[tid * 8 + q];
+                    tot += sacc;
+                }
+                __syncthreads();
             }
-#pragma unroll
-            for (int k = 0; k < 27; k++) acc[k] = wave_sum_f64(acc[k]);
-            __syncthreads();
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 27; k++) cred[wid * 27 + k] = acc[k];
-            }
-            __syncthreads();
             if (tid < 27) {
-                double s = cred[tid];
-                for (int w = 1; w < BA_NW; w++) s += cred[w * 27 + tid];
                 if (tid < 21) {
                     int a = 0, k = tid;
                     while (k >= 6 - a) { k -= 6 - a; a++; }
                     const int b = a + k;
-                    S[(size_t)(6 * c + a) * m + 6 * c + b] = s;
-                    S[(size_t)(6 * c + b) * m + 6 * c + a] = s;
-                } else rhs[6 * c + (tid - 21)] = s;
+                    S[(size_t)(6 * c + a) * m + 6 * c + b] = tot;
+                    S[(size_t)(6 * c + b) * m + 6 * c + a] = tot;
+                } else rhs[6 * c + (tid - 21)] = tot;
             }
-            __syncthreads();
         }
+        __syncthreads();
+        STAMP(1);
         // ================= LM diagonal ======================================================================================
         if (!st.reuse_diag) {
             for (int i = tid; i < m; i += BA_T) diag[i] = fmin(fmax(S[(size_t)i * m + i], 1e-6), 1e32);
@@ -314,6 +420,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         }
         __syncthreads();
         for (int i = tid; i < m; i += BA_T) S[(size_t)i * m + i] += D2[i];
+        STAMP(2);
         // ================= point blocks: E^-1, g, dense rows of Yd and [Wd | g] =============================================
         for (int i = tid; i < krows * ldw; i += BA_T) { Yd[i] = 0.0; Wd[i] = 0.0; }
         if (tid == 0) st.chol_fail = 0;
@@ -360,7 +467,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
                 e2 = (e2 - L[6] * e0 - L[7] * e1) / L[8];
                 e2 = e2 / L[8];
                 e1 = (e1 - L[7] * e2) / L[4];
-                e0 = (e0 - L[3] * e1 - L[6] * e2) / L[0];
+                e0 = (e0 - L[6] * e2 - L[3] * e1) / L[0];
                 Ei[0 * 3 + cI] = e0; Ei[1 * 3 + cI] = e1; Ei[2 * 3 + cI] = e2;
             }
 #pragma unroll
@@ -370,6 +477,8 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
             for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
                 const int i = A.pobs_list[e];
                 const int c = A.cam_idx[i];
+                bool dup = false;
+                for (int e2 = A.pobs_start[p]; e2 < e; e2++) dup = dup || (A.cam_idx[A.pobs_list[e2]] == c);
                 const double* Jc = J + (size_t)i * 18;
                 const double* Jp = Jc + 12;
 #pragma unroll
@@ -380,12 +489,15 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
 #pragma unroll
                     for (int b = 0; b < 3; b++) {
                         const double y = w3[0] * Ei[0 * 3 + b] + w3[1] * Ei[1 * 3 + b] + w3[2] * Ei[2 * 3 + b];
-                        Wd[(size_t)(3 * p + b) * ldw + 6 * c + a] += w3[b];
-                        Yd[(size_t)(3 * p + b) * ldw + 6 * c + a] += y;
+                        double* wp = &Wd[(size_t)(3 * p + b) * ldw + 6 * c + a];
+                        double* yp = &Yd[(size_t)(3 * p + b) * ldw + 6 * c + a];
+                        if (dup) { *wp += w3[b]; *yp += y; }      // two features of one frame on the same landmark (rare)
+                        else { *wp = w3[b]; *yp = y; }             // rows were zeroed: plain stores, no load in the way
                     }
                 }
             }
         }
+        STAMP(3);
         // gradient max norm of the unscaled problem (cameras from rhs, points from g)
         for (int i = tid; i < m; i += BA_T) gmax_p = fmax(gmax_p, fabs(rhs[i] / scale[i]));
         const double gm = block_max(gmax_p, red);
@@ -395,6 +507,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
 
         bool valid = !st.chol_fail;
         if (valid) {
+            STAMP(4);
             // ================= Schur complement on FP64 MFMA: G = Yd^T [Wd | g]  (m_pad x ncol_pad, K = krows) =============
             const int tr = A.tiles_r, tc = A.tiles_c, ks = A.kslices, kper = A.kper;
             const int items = tr * tc * ks;
@@ -405,6 +518,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
                 v4d acc = {0, 0, 0, 0};
                 const double* ya = Yd + (size_t)(lane >> 4) * ldw + ti * 16 + (lane & 15);
                 const double* wb = Wd + (size_t)(lane >> 4) * ldw + tj * 16 + (lane & 15);
+#pragma unroll 16
                 for (int k = k0; k < k1; k += 4) {
                     const double a = ya[(size_t)k * ldw];
                     const double b = wb[(size_t)k * ldw];
@@ -424,41 +538,61 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
                 else rhs[a] -= g;
             }
             __syncthreads();
-            // ================= Cholesky of S (right-looking, in place, lower) ================================================
-            for (int j = 0; j < m; j++) {
-                if (tid == 0) {
+            STAMP(5);
+            // ================= Cholesky of S + triangular solves: wave 0 only, wave-synchronous on LDS =====================
+            // lane l owns rows l, l+64, ... ; element (i,k) receives its updates in ascending j, the same order as a
+            // left-looking factorisation; forward substitution subtracts in ascending column order, backward in descending.
+            if (wid == 0) {
+                bool fail = false;
+                for (int j = 0; j < m && !fail; j++) {
                     const double d = S[(size_t)j * m + j];
-                    if (!(d > 0.0)) st.chol_fail = 1;
-                    else S[(size_t)j * m + j] = sqrt(d);
+                    if (!(d > 0.0)) { fail = true; break; }
+                    const double dj = sqrt(d);
+                    WAVE_SYNC();
+                    for (int i = lane; i < m; i += 64) {
+                        if (i == j) S[(size_t)j * m + j] = dj;
+                        else if (i > j) S[(size_t)i * m + j] /= dj;
+                    }
+                    WAVE_SYNC();
+                    {   // trailing update of the lower triangle, one element per lane-step
+                        const int rem = m - j - 1;
+                        for (int e = lane; e < rem * rem; e += 64) {
+                            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+                            if (k <= i) S[(size_t)i * m + k] -= S[(size_t)i * m + j] * S[(size_t)k * m + j];
+                        }
+                    }
+                    WAVE_SYNC();
                 }
-                __syncthreads();
-                if (st.chol_fail) break;
-                const double dj = S[(size_t)j * m + j];
-                for (int i = j + 1 + tid; i < m; i += BA_T) S[(size_t)i * m + j] /= dj;
-                __syncthreads();
-                const int rem = m - j - 1;
-                for (int e = tid; e < rem * rem; e += BA_T) {
-                    const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-                    if (k <= i) S[(size_t)i * m + k] -= S[(size_t)i * m + j] * S[(size_t)k * m + j];
+                if (fail) { if (lane == 0) st.chol_fail = 1; }
+                else {
+                    for (int i = lane; i < m; i += 64) stepc[i] = rhs[i];
+                    WAVE_SYNC();
+                    for (int j = 0; j < m; j++) {
+                        const double yj = stepc[j] / S[(size_t)j * m + j];
+                        WAVE_SYNC();
+                        for (int i = lane; i < m; i += 64) {
+                            if (i == j) stepc[j] = yj;
+                            else if (i > j) stepc[i] -= S[(size_t)i * m + j] * yj;
+                        }
+                        WAVE_SYNC();
+                    }
+                    for (int i = m - 1; i >= 0; i--) {
+                        const double xi = stepc[i] / S[(size_t)i * m + i];
+                        WAVE_SYNC();
+                        for (int k = lane; k < m; k += 64) {
+                            if (k == i) stepc[i] = xi;
+                            else if (k < i) stepc[k] -= S[(size_t)i * m + k] * xi;
+                        }
+                        WAVE_SYNC();
+                    }
                 }
-                __syncthreads();
             }
+            __syncthreads();
             valid = !st.chol_fail;
         }
         if (valid) {
-            // forward / backward substitution (thread 0; m <= 192)
-            if (tid == 0) {
-                for (int i = 0; i < m; i++) {
-                    double v = rhs[i];
-                    for (int k = 0; k < i; k++) v -= S[(size_t)i * m + k] * step[k];
-                    step[i] = v / S[(size_t)i * m + i];
-                }
-                for (int i = m - 1; i >= 0; i--) {
-                    double v = step[i];
-                    for (int k = i + 1; k < m; k++) v -= S[(size_t)k * m + i] * step[k];
-                    step[i] = v / S[(size_t)i * m + i];
-                }
-            }
+            STAMP(6);
+            for (int i = tid; i < m; i += BA_T) step[i] = stepc[i];
             __syncthreads();
             // point back-substitution: y_p = E^-1 (g_p - sum W^T y_c)
             for (int p = tid; p < np; p += BA_T) {
@@ -481,6 +615,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
             __syncthreads();
             for (int i = tid; i < n; i += BA_T) step[i] = -step[i];
             __syncthreads();
+            STAMP(7);
             // model cost change = -(J step)^T (r + J step / 2)
             double mc = 0;
             for (int i = tid; i < nobs; i += BA_T) {
@@ -511,6 +646,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
             if (st.done) break;
             continue;
         }
+        STAMP(8);
         // ================= candidate, tolerances, accept / reject =============================================================
         double sn = 0;
         for (int i = tid; i < n; i += BA_T) {
@@ -520,10 +656,12 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         }
         sn = block_sum(sn, red);
         double cpart = 0;
+        if (tid < nc) cam_rot_setup(cand + 6 * tid, crot[tid]);
+        __syncthreads();
         for (int i = tid; i < nobs; i += BA_T) {
             double r[2];
             const int c = A.cam_idx[i], p = A.pt_idx[i];
-            projection_residual(cand + 6 * c, cand + 6 * nc + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, nullptr, nullptr, false);
+            projection_residual_pre(crot[c], cand + 6 * c, cand + 6 * nc + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, nullptr, nullptr, false);
             double rho0, rho1;
             huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
             cpart += 0.5 * rho0;
@@ -553,6 +691,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         }
         __syncthreads();
         if (st.done) break;
+        STAMP(9);
         if (st.need_eval == 2) {
             for (int i = tid; i < n; i += BA_T) x[i] = cand[i];
             __syncthreads();
@@ -563,6 +702,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
     __syncthreads();
     for (int i = tid; i < 6 * nc; i += BA_T) A.cams[i] = x[i];
     for (int i = tid; i < 3 * np; i += BA_T) A.pts[i] = x[6 * nc + i];
+    if (A.stamps && tid == 0) { A.stamps[28] = wall_clock64() - A.stamps[30]; A.stamps[29] = __builtin_readcyclecounter() - A.stamps[31]; }
     if (tid == 0) {
         A.summary[1] = st.x_cost; A.summary[2] = st.iter; A.summary[3] = st.successful; A.summary[4] = st.termination;
     }
@@ -571,11 +711,21 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
 hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,
                                const int* pt_idx, int nobs, const double* K, double* out_r, double* out_J) {
     if (nobs <= 0) return hipSuccess;
+    ProfScope ps(K_BA_RESID, s);
     hipLaunchKernelGGL(k_ba_residuals, dim3((nobs + 255) / 256), dim3(256), 0, s, cams, pts, obs, cam_idx, pt_idx, nobs, K, out_r, out_J);
     return hipGetLastError();
 }
 hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A) {
-    hipLaunchKernelGGL(k_ba_lm, dim3(1), dim3(BA_T), 0, s, A);
+    const int m = 6 * A.nc;
+    const size_t shm = ((size_t)m * m + 2 * (size_t)m + 27 * CB_CH) * sizeof(double);   // reduced camera system + camera-block tile
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    ProfScope ps(K_BA_LM, s);
+    hipLaunchKernelGGL(k_ba_lm, dim3(1), dim3(BA_T), shm, s, A);
     return hipGetLastError();
 }
 

@@ -6,51 +6,78 @@
 // "best so far / niters = RANSACUpdateNumIters(...)" scan in iteration order gives exactly the sequential result.
 #include "pmv_ctx.h"
 #include "backend.h"
+#include "pmv_prof.h"
 #include <float.h>
 
 namespace pmv {
 
 // ---- small dense routines (device copies of the fixed-choice algorithms documented in DESIGN.md) -------------------------
-__device__ inline void d_jacobi_eig(double* A, int n, double* w, double* V) {   // cyclic Jacobi, ascending eigenvalues
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+// cyclic Jacobi, ascending eigenvalues. N is a compile-time constant and every loop over matrix indices is fully unrolled so
+// that A, V and w stay in registers (with a run-time n they live in scratch memory and every access is an L2 round trip).
+template <int N>
+__device__ inline void d_jacobi_eig(double* A, double* w, double* V) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < N; j++) V[i * N + j] = (i == j) ? 1.0 : 0.0;
+    double tol_abs = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) tol_abs += fabs(A[i * N + i]);
+    tol_abs *= 1e-17;
     for (int sweep = 0; sweep < 30; sweep++) {
         int rotated = 0;
-        for (int p = 0; p < n - 1; p++)
-            for (int q = p + 1; q < n; q++) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue;
-                const double app = A[p * n + p], aqq = A[q * n + q];
-                if (fabs(apq) <= 1e-18 * (fabs(app) + fabs(aqq))) { A[p * n + q] = A[q * n + p] = 0.0; continue; }
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < n; k++) {
-                    if (k == p || k == q) continue;
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    const double nkp = c * akp - s * akq, nkq = s * akp + c * akq;
-                    A[k * n + p] = A[p * n + k] = nkp;
-                    A[k * n + q] = A[q * n + k] = nkq;
+#pragma unroll
+        for (int p = 0; p < N - 1; p++)
+#pragma unroll
+            for (int q = p + 1; q < N; q++) {
+                const double apq = A[p * N + q];
+                if (apq != 0.0) {
+                    const double app = A[p * N + p], aqq = A[q * N + q];
+                    if (fabs(apq) <= tol_abs) { A[p * N + q] = A[q * N + p] = 0.0; }
+                    else {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                        for (int k = 0; k < N; k++) {
+                            if (k == p || k == q) continue;
+                            const double akp = A[k * N + p], akq = A[k * N + q];
+                            const double nkp = c * akp - s * akq, nkq = s * akp + c * akq;
+                            A[k * N + p] = A[p * N + k] = nkp;
+                            A[k * N + q] = A[q * N + k] = nkq;
+                        }
+                        A[p * N + p] = app - t * apq;
+                        A[q * N + q] = aqq + t * apq;
+                        A[p * N + q] = A[q * N + p] = 0.0;
+#pragma unroll
+                        for (int k = 0; k < N; k++) {
+                            const double vkp = V[k * N + p], vkq = V[k * N + q];
+                            V[k * N + p] = c * vkp - s * vkq;
+                            V[k * N + q] = s * vkp + c * vkq;
+                        }
+                        rotated++;
+                    }
                 }
-                A[p * n + p] = app - t * apq;
-                A[q * n + q] = aqq + t * apq;
-                A[p * n + q] = A[q * n + p] = 0.0;
-                for (int k = 0; k < n; k++) {
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - s * vkq;
-                    V[k * n + q] = s * vkp + c * vkq;
-                }
-                rotated++;
             }
         if (!rotated) break;
     }
-    for (int i = 0; i < n; i++) w[i] = A[i * n + i];
-    for (int i = 0; i < n - 1; i++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) w[i] = A[i * N + i];
+    // ascending selection sort as a fixed compare-exchange network over (i, j > i): same result as "find min, swap"
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+        // index of the minimum of w[i..N-1] (first occurrence), then swap columns i and m
         int m = i;
-        for (int j = i + 1; j < n; j++) if (w[j] < w[m]) m = j;
-        if (m != i) {
-            double t = w[i]; w[i] = w[m]; w[m] = t;
-            for (int k = 0; k < n; k++) { t = V[k * n + i]; V[k * n + i] = V[k * n + m]; V[k * n + m] = t; }
+        double wm = w[i];
+#pragma unroll
+        for (int j = i + 1; j < N; j++) if (w[j] < wm) { wm = w[j]; m = j; }
+#pragma unroll
+        for (int j = i + 1; j < N; j++) {
+            if (j == m) {
+                double t = w[i]; w[i] = w[j]; w[j] = t;
+#pragma unroll
+                for (int k = 0; k < N; k++) { t = V[k * N + i]; V[k * N + i] = V[k * N + j]; V[k * N + j] = t; }
+            }
         }
     }
 }
@@ -63,7 +90,7 @@ __device__ inline void d_svd3(const double A[9], double U[9], double s[3], doubl
             for (int k = 0; k < 3; k++) acc += A[k * 3 + i] * A[k * 3 + j];
             AtA[i * 3 + j] = acc;
         }
-    d_jacobi_eig(AtA, 3, w, Ve);
+    d_jacobi_eig<3>(AtA, w, Ve);
     for (int k = 0; k < 3; k++) {
         const int src = 2 - k;
         s[k] = sqrt(w[src] > 0 ? w[src] : 0.0);
@@ -126,30 +153,41 @@ __device__ inline void d_rodrigues_m2v(const double Rin[9], double r[3]) {
     r[0] = rx; r[1] = ry; r[2] = rz;
 }
 
-__device__ inline void d_pinv_solve(const double* A, int m, int n, const double* b, double* x) {
-    double AtA[36], w[6], V[36], Atb[6];
-    for (int i = 0; i < n; i++) {
-        for (int j = 0; j < n; j++) {
+template <int M, int N>
+__device__ inline void d_pinv_solve(const double* A, const double* b, double* x) {
+    double AtA[N * N], w[N], V[N * N], Atb[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
             double acc = 0;
-            for (int k = 0; k < m; k++) acc += A[k * n + i] * A[k * n + j];
-            AtA[i * n + j] = acc;
+#pragma unroll
+            for (int k = 0; k < M; k++) acc += A[k * N + i] * A[k * N + j];
+            AtA[i * N + j] = acc;
         }
         double acc = 0;
-        for (int k = 0; k < m; k++) acc += A[k * n + i] * b[k];
+#pragma unroll
+        for (int k = 0; k < M; k++) acc += A[k * N + i] * b[k];
         Atb[i] = acc;
     }
-    d_jacobi_eig(AtA, n, w, V);
+    d_jacobi_eig<N>(AtA, w, V);
     double ssum = 0;
-    for (int i = 0; i < n; i++) ssum += sqrt(w[i] > 0 ? w[i] : 0.0);
+#pragma unroll
+    for (int i = 0; i < N; i++) ssum += sqrt(w[i] > 0 ? w[i] : 0.0);
     const double thr = 2 * DBL_EPSILON * ssum;
-    for (int i = 0; i < n; i++) x[i] = 0;
-    for (int k = 0; k < n; k++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
         const double sg = sqrt(w[k] > 0 ? w[k] : 0.0);
-        if (!(sg > thr)) continue;
-        double proj = 0;
-        for (int i = 0; i < n; i++) proj += V[i * n + k] * Atb[i];
-        proj /= w[k];
-        for (int i = 0; i < n; i++) x[i] += V[i * n + k] * proj;
+        if (sg > thr) {
+            double proj = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) proj += V[i * N + k] * Atb[i];
+            proj /= w[k];
+#pragma unroll
+            for (int i = 0; i < N; i++) x[i] += V[i * N + k] * proj;
+        }
     }
 }
 
@@ -166,6 +204,8 @@ struct EpnpShared {
     int P[6], Q[6];
     double pws[15], us[10], alphas[20], cws[12];
     double v4[48];
+    double L[60], rho[6];
+    double case_err[3], case_R[27], case_t[9];
     int rotated;
 };
 
@@ -324,7 +364,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
                 for (int i = 0; i < n; i++) acc += (sh.pws[3 * i + a] - cws[a]) * (sh.pws[3 * i + b] - cws[b]);
                 C[a * 3 + b] = acc;
             }
-        d_jacobi_eig(C, 3, w, V);
+        d_jacobi_eig<3>(C, w, V);
         for (int i = 1; i < 4; i++) {
             const int src = 3 - i;
             const double k = sqrt((w[src] > 0 ? w[src] : 0.0) / n);
@@ -374,6 +414,9 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
     }
     __syncthreads();
     // parallel-order (round-robin) Jacobi: 6 disjoint rotations per round
+    double tol_abs = 0;
+    for (int i = 0; i < 12; i++) tol_abs += fabs(sh.A[i * 13]);
+    tol_abs *= 1e-17;
     for (int sweep = 0; sweep < 30; sweep++) {
         if (lane == 0) sh.rotated = 0;
         __syncthreads();
@@ -386,7 +429,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
                 const int p = a < b ? a : b, q = a < b ? b : a;
                 sh.P[g] = p; sh.Q[g] = q;
                 const double apq = sh.A[p * 12 + q], app = sh.A[p * 12 + p], aqq = sh.A[q * 12 + q];
-                if (apq == 0.0 || fabs(apq) <= 1e-18 * (fabs(app) + fabs(aqq))) { sh.C[g] = 1.0; sh.S[g] = 0.0; }
+                if (fabs(apq) <= tol_abs) { sh.C[g] = 1.0; sh.S[g] = 0.0; }
                 else {
                     const double theta = (aqq - app) / (2.0 * apq);
                     const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
@@ -435,7 +478,8 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
         for (int i = 0; i < 4; i++)
             for (int k = 0; k < 12; k++) sh.v4[i * 12 + k] = sh.V[k * 12 + ord[i]];
         // compute_L_6x10, compute_rho
-        double L[60], rho[6];
+        double* L = sh.L;
+        double* rho = sh.rho;
         {
             double dv[4][6][3];
             for (int i = 0; i < 4; i++) {
@@ -466,46 +510,54 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
             rho[0] = d_dist2(cws, cws + 3); rho[1] = d_dist2(cws, cws + 6); rho[2] = d_dist2(cws, cws + 9);
             rho[3] = d_dist2(cws + 3, cws + 6); rho[4] = d_dist2(cws + 3, cws + 9); rho[5] = d_dist2(cws + 6, cws + 9);
         }
-        double betas[4], bestR[9], bestt[3], best_err = 0;
-        for (int N = 1; N <= 3; N++) {
-            if (N == 1) {
-                double l4[24], b4[4];
-                for (int i = 0; i < 6; i++) { l4[i * 4] = L[i * 10]; l4[i * 4 + 1] = L[i * 10 + 1]; l4[i * 4 + 2] = L[i * 10 + 3]; l4[i * 4 + 3] = L[i * 10 + 6]; }
-                d_pinv_solve(l4, 6, 4, rho, b4);
-                if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
-                else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
-            } else if (N == 2) {
-                double l3[18], b3[3];
-                for (int i = 0; i < 6; i++) { l3[i * 3] = L[i * 10]; l3[i * 3 + 1] = L[i * 10 + 1]; l3[i * 3 + 2] = L[i * 10 + 2]; }
-                d_pinv_solve(l3, 6, 3, rho, b3);
-                if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
-                else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
-                if (b3[1] < 0) betas[0] = -betas[0];
-                betas[2] = 0.0; betas[3] = 0.0;
-            } else {
-                double l5[30], b5[5];
-                for (int i = 0; i < 6; i++)
-                    for (int j = 0; j < 5; j++) l5[i * 5 + j] = L[i * 10 + j];
-                d_pinv_solve(l5, 6, 5, rho, b5);
-                if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
-                else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
-                if (b5[1] < 0) betas[0] = -betas[0];
-                betas[2] = b5[3] / betas[0];
-                betas[3] = 0.0;
-            }
-            epnp_gauss_newton(L, rho, betas);
-            double R[9], t[3];
-            const double e = epnp_R_and_t(sh, betas, fu, fv, uc, vc, R, t);
-            // N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3;
-            if (N == 1 || e < best_err) {
-                best_err = e;
-                for (int i = 0; i < 9; i++) bestR[i] = R[i];
-                for (int i = 0; i < 3; i++) bestt[i] = t[i];
-            }
+    }
+    __syncthreads();
+    // the three EPnP cases (N = 1, 2, 3 null-space vectors) are independent: lanes 0..2 evaluate them side by side
+    if (lane < 3) {
+        const int N = lane + 1;
+        double L[60], rho[6], betas[4];
+        for (int i = 0; i < 60; i++) L[i] = sh.L[i];
+        for (int i = 0; i < 6; i++) rho[i] = sh.rho[i];
+        if (N == 1) {
+            double l4[24], b4[4];
+            for (int i = 0; i < 6; i++) { l4[i * 4] = L[i * 10]; l4[i * 4 + 1] = L[i * 10 + 1]; l4[i * 4 + 2] = L[i * 10 + 3]; l4[i * 4 + 3] = L[i * 10 + 6]; }
+            d_pinv_solve<6, 4>(l4, rho, b4);
+            if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
+            else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
+        } else if (N == 2) {
+            double l3[18], b3[3];
+            for (int i = 0; i < 6; i++) { l3[i * 3] = L[i * 10]; l3[i * 3 + 1] = L[i * 10 + 1]; l3[i * 3 + 2] = L[i * 10 + 2]; }
+            d_pinv_solve<6, 3>(l3, rho, b3);
+            if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
+            else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
+            if (b3[1] < 0) betas[0] = -betas[0];
+            betas[2] = 0.0; betas[3] = 0.0;
+        } else {
+            double l5[30], b5[5];
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 5; j++) l5[i * 5 + j] = L[i * 10 + j];
+            d_pinv_solve<6, 5>(l5, rho, b5);
+            if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+            else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+            if (b5[1] < 0) betas[0] = -betas[0];
+            betas[2] = b5[3] / betas[0];
+            betas[3] = 0.0;
         }
+        epnp_gauss_newton(L, rho, betas);
+        double R[9], t[3];
+        sh.case_err[lane] = epnp_R_and_t(sh, betas, fu, fv, uc, vc, R, t);
+        for (int i = 0; i < 9; i++) sh.case_R[lane * 9 + i] = R[i];
+        for (int i = 0; i < 3; i++) sh.case_t[lane * 3 + i] = t[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        // N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3;
+        int N = 0;
+        if (sh.case_err[1] < sh.case_err[0]) N = 1;
+        if (sh.case_err[2] < sh.case_err[N]) N = 2;
         double rv[3];
-        d_rodrigues_m2v(bestR, rv);
-        for (int i = 0; i < 3; i++) { models[h * 6 + i] = rv[i]; models[h * 6 + 3 + i] = bestt[i]; }
+        d_rodrigues_m2v(sh.case_R + 9 * N, rv);
+        for (int i = 0; i < 3; i++) { models[h * 6 + i] = rv[i]; models[h * 6 + 3 + i] = sh.case_t[N * 3 + i]; }
     }
 }
 
@@ -771,8 +823,11 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
                       double* d_rt_out, int* d_inliers, int* d_info) {
-    hipLaunchKernelGGL(k_pnp_hyp, dim3(n_hyp), dim3(64), 0, s, d_obj, d_img, d_samples, d_K, d_models);
-    hipLaunchKernelGGL(k_pnp_score, dim3(n_hyp), dim3(256), 0, s, d_obj, d_img, m, d_K, d_models, thr, d_masks, d_counts);
+    { ProfScope ps(K_PNP_HYP, s);
+    hipLaunchKernelGGL(k_pnp_hyp, dim3(n_hyp), dim3(64), 0, s, d_obj, d_img, d_samples, d_K, d_models); }
+    { ProfScope ps(K_PNP_SCORE, s);
+    hipLaunchKernelGGL(k_pnp_score, dim3(n_hyp), dim3(256), 0, s, d_obj, d_img, m, d_K, d_models, thr, d_masks, d_counts); }
+    ProfScope ps3(K_PNP_REFIT, s);
     hipLaunchKernelGGL(k_pnp_select_refit, dim3(1), dim3(RF_T), 0, s, d_obj, d_img, m, d_K, d_models, d_masks, d_counts, n_hyp,
                        confidence, d_rt_out, d_inliers, d_info);
     return hipGetLastError();

@@ -7,6 +7,7 @@
 using namespace pmv;
 
 static thread_local char g_create_err[512] = "";
+thread_local pmv::Profiler* pmv::tl_prof = nullptr;
 
 void pmv::set_err(pmv_ctx* c, const char* fmt, ...) {
     va_list ap;
@@ -99,6 +100,7 @@ void pmv_ctx_destroy(pmv_ctx* c) {
     if (c->s_front) hipStreamSynchronize(c->s_front);
     if (c->s_back) hipStreamSynchronize(c->s_back);
     backend_destroy(c);
+    c->prof.destroy();
     hipFree(c->d_slots); hipFree(c->d_prev_xy); hipFree(c->d_out_xy); hipFree(c->d_status); hipFree(c->d_err);
     hipHostFree(c->h_prev_xy); hipHostFree(c->h_out_xy); hipHostFree(c->h_status); hipHostFree(c->h_err);
     hipFree(c->d_cells); hipFree(c->d_eig); hipFree(c->d_cellmax); hipFree(c->d_det_xy); hipFree(c->d_det_score);
@@ -149,6 +151,7 @@ int pmv_frames_stage(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, i
 
 int pmv_frames_build(pmv_ctx* ctx, int first_slot, int n) {
     REQ(ctx, PMV_ERR_INVALID, "null ctx");
+    tl_prof = &ctx->prof;
     REQ(first_slot >= 0 && n >= 1 && first_slot + n <= ctx->n_slots, PMV_ERR_CAPACITY, "pmv_frames_build: slot range");
     CKC(hipSetDevice(ctx->device));
     // consecutive slots with identical geometry are built in one batched launch per level
@@ -171,6 +174,7 @@ int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, 
     REQ(ctx && gray, PMV_ERR_INVALID, "pmv_frame_upload: null argument");
     REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "pmv_frame_upload: slot %d out of range", slot);
     REQ(w >= 40 && h >= 40 && w <= ctx->max_w && h <= ctx->max_h && stride >= w, PMV_ERR_CAPACITY, "pmv_frame_upload: frame %dx%d outside capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+    tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     PyrLayout L = layout_for(ctx, w, h);
     CKC(hipMemcpy2DAsync(ctx->d_slots + (size_t)slot * L.slot_bytes + L.gray_off, w, gray, stride, w, h, hipMemcpyHostToDevice, ctx->s_front));
@@ -211,6 +215,7 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     REQ(L.n_levels > 0 && L2.n_levels > 0, PMV_ERR_INVALID, "pmv_lk_track: slot has no pyramid");
     REQ(L.w[0] == L2.w[0] && L.h[0] == L2.h[0], PMV_ERR_INVALID, "pmv_lk_track: frame sizes differ");
     if (n == 0) return PMV_OK;
+    tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     memcpy(ctx->h_prev_xy, prev_xy, (size_t)n * 8);
     CKC(hipMemcpyAsync(ctx->d_prev_xy, ctx->h_prev_xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->s_front));
@@ -248,6 +253,7 @@ int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int m
     int rc = check_cells(ctx, slot, cells, n_cells, max_per_cell);
     if (rc) return rc;
     REQ(out_xy && out_count, PMV_ERR_INVALID, "pmv_detect_gftt: null output");
+    tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     const PyrLayout& L = ctx->slot_layout[slot];
     CKC(hipMemcpyAsync(ctx->d_cells, cells, (size_t)n_cells * 16, hipMemcpyHostToDevice, ctx->s_front));
@@ -269,6 +275,7 @@ int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, 
     int rc = check_cells(ctx, slot, cells, n_cells, max_per_cell);
     if (rc) return rc;
     REQ(out_xy && out_score && out_count, PMV_ERR_INVALID, "pmv_detect_shitomasi: null output");
+    tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     const PyrLayout& L = ctx->slot_layout[slot];
     CKC(hipMemcpyAsync(ctx->d_cells, cells, (size_t)n_cells * 16, hipMemcpyHostToDevice, ctx->s_front));
@@ -284,6 +291,35 @@ int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, 
     memcpy(out_xy, ctx->h_det_xy, nxy);
     memcpy(out_score, ctx->h_det_score, nxy);
     memcpy(out_count, ctx->h_det_count, (size_t)n_cells * 4);
+    return PMV_OK;
+}
+
+// ---- per-kernel HIP-event timing -------------------------------------------------------------------------------------
+int pmv_prof_enable(pmv_ctx* ctx, int on) {
+    REQ(ctx, PMV_ERR_INVALID, "null ctx");
+    CKC(hipSetDevice(ctx->device));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    CKC(hipStreamSynchronize(ctx->s_back));
+    if (on) for (int i = 0; i < K_COUNT; i++) { ctx->prof.used[i] = 0; ctx->prof.dropped[i] = 0; }
+    ctx->prof.enabled = on != 0;
+    return PMV_OK;
+}
+int pmv_prof_kernel_count(void) { return K_COUNT; }
+const char* pmv_prof_kernel_name(int id) { return kernel_name(id); }
+int pmv_prof_read(pmv_ctx* ctx, int id, int* launches, double* total_ms, double* max_ms) {
+    REQ(ctx && id >= 0 && id < K_COUNT && launches && total_ms && max_ms, PMV_ERR_INVALID, "pmv_prof_read: bad argument");
+    CKC(hipSetDevice(ctx->device));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    CKC(hipStreamSynchronize(ctx->s_back));
+    double tot = 0, mx = 0;
+    const int n = ctx->prof.used[id] / 2;
+    for (int i = 0; i < n; i++) {
+        float ms = 0;
+        CKC(hipEventElapsedTime(&ms, ctx->prof.ev[id][2 * i], ctx->prof.ev[id][2 * i + 1]));
+        tot += ms;
+        if (ms > mx) mx = ms;
+    }
+    *launches = n; *total_ms = tot; *max_ms = mx;
     return PMV_OK;
 }
 

@@ -4,6 +4,7 @@
 //   * LK: every window sum is an exact integer (per-lane int32 partials, 64-bit wave reduction), rounded once to f32;
 //   * GFTT: float32 ops in a fixed order, compiled with -ffp-contract=off; the 3x3 box sum is a 9-term double sum.
 #include "pmv_device.h"
+#include "pmv_prof.h"
 #include <float.h>
 
 namespace pmv {
@@ -60,11 +61,13 @@ __global__ __launch_bounds__(256) void k_pyrdown(uint8_t* slots, PyrLayout L, in
 
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n) {
     dim3 grid((L.w[0] + 2 * PAD + 1023) / 1024, L.h[0] + 2 * PAD, n);
+    ProfScope ps(K_PAD0, s);
     hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, s, slots, L, first_slot);
     return hipGetLastError();
 }
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int ld, int first_slot, int n) {
     dim3 grid((L.w[ld] + 2 * PAD + 1023) / 1024, L.h[ld] + 2 * PAD, n);
+    ProfScope ps(K_PYRDOWN, s);
     hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, slots, L, ld, first_slot);
     return hipGetLastError();
 }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
                 p0 = p0n; p1 = p1n; q0 = q0n; q1 = q1n;
             }
         }
-        const long long sA11 = wave_sum_i64(a11), sA12 = wave_sum_i64(a12), sA22 = wave_sum_i64(a22);
+        const long long sA11 = wave_sum_i32_wide(a11), sA12 = wave_sum_i32_wide(a12), sA22 = wave_sum_i32_wide(a22);
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * W * W);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
                     p0 = p0n; p1 = p1n;
                 }
             }
-            const float fb1 = (float)wave_sum_i64(b1) * FLT_SCALE, fb2 = (float)wave_sum_i64(b2) * FLT_SCALE;
+            const float fb1 = (float)wave_sum_i32_wide(b1) * FLT_SCALE, fb2 = (float)wave_sum_i32_wide(b2) * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nx += dx; ny += dy;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
                     e += diff < 0 ? -diff : diff;
                     p0 = p0n; p1 = p1n;
                 }
-                err = (float)wave_sum_i64(e) * (1.f / (32 * W * W));
+                err = (float)wave_sum_i32(e) * (1.f / (32 * W * W));   // <= 1024 * 8160 fits int32
             }
         }
     }
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
                      const float* d_prev_xy, int n, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err) {
     if (n <= 0) return hipSuccess;
+    ProfScope ps(K_LK, s);
     hipLaunchKernelGGL(k_lk, dim3(n), dim3(64), 0, s, prev_slot, next_slot, L, d_prev_xy, n, P, d_out_xy, d_status, d_err);
     return hipGetLastError();
 }
@@ -446,8 +450,16 @@ hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, c
                        int* d_out_xy, int* d_out_count, int* d_flags) {
     hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned) * n_cells, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gftt_eig, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_eig, d_cellmax);
+    { ProfScope ps(K_GFTT_EIG, s);
+    hipLaunchKernelGGL(k_gftt_eig, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_eig, d_cellmax); }
+    ProfScope ps2(K_GFTT_SELECT, s);
     const size_t shm = GFTT_CAP * 8 + 16 * 8 + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute((const void*)k_gftt_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL(k_gftt_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_eig, d_cellmax, max_per_cell,
                        quality, min_dist, d_out_xy, d_out_count, d_flags);
     return hipGetLastError();
@@ -585,8 +597,16 @@ hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slot, const PyrLayout&
                             int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags) {
     hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned long long) * n_cells, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_st_resp, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_resp, d_cellmax);
+    { ProfScope ps(K_ST_RESP, s);
+    hipLaunchKernelGGL(k_st_resp, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_resp, d_cellmax); }
+    ProfScope ps2(K_ST_SELECT, s);
     const size_t shm = ST_CAP * 12 + 16 * 12 + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute((const void*)k_st_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL(k_st_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_resp, d_cellmax, max_per_cell,
                        quality, d_out_xy, d_out_score, d_out_count, d_flags);
     return hipGetLastError();

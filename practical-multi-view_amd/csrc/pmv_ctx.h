@@ -1,6 +1,7 @@
 // Internal context definition shared by the C-ABI translation units.
 #pragma once
 #include "pmv_device.h"
+#include "pmv_prof.h"
 #include "../../include/pmv_hip.h"
 #include <vector>
 
@@ -31,6 +32,7 @@ struct pmv_ctx {
     int *h_det_xy = nullptr, *h_det_count = nullptr;
     double* h_det_score = nullptr;
     pmv::BackendBuffers* be = nullptr;
+    pmv::Profiler prof;
     char err[512] = "";
 };
 

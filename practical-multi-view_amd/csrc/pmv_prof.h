@@ -1,0 +1,50 @@
+// Per-kernel HIP-event timing (bench.py's roofline leg): events are recorded around every launch of a kernel class on the
+// stream it is launched on and read back after the timed region; nothing synchronises while recording.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace pmv {
+
+enum KernelId { K_PAD0 = 0, K_PYRDOWN, K_LK, K_GFTT_EIG, K_GFTT_SELECT, K_ST_RESP, K_ST_SELECT, K_PNP_HYP, K_PNP_SCORE, K_PNP_REFIT,
+                K_BA_LM, K_BA_RESID, K_COUNT };
+
+inline const char* kernel_name(int id) {
+    static const char* n[K_COUNT] = {"k_pad_level0", "k_pyrdown", "k_lk", "k_gftt_eig", "k_gftt_select", "k_st_resp", "k_st_select",
+                                     "k_pnp_hyp", "k_pnp_score", "k_pnp_select_refit", "k_ba_lm", "k_ba_residuals"};
+    return (id >= 0 && id < K_COUNT) ? n[id] : "?";
+}
+
+struct Profiler {
+    static constexpr int CAP = 8192;   // launches per kernel class between resets
+    bool enabled = false;
+    std::vector<hipEvent_t> ev[K_COUNT];
+    int used[K_COUNT] = {0};
+    long dropped[K_COUNT] = {0};
+    hipEvent_t* next(int id) {
+        if (ev[id].empty()) {
+            ev[id].resize(2 * CAP);
+            for (auto& e : ev[id]) (void)hipEventCreate(&e);
+        }
+        if (used[id] + 2 > 2 * CAP) { dropped[id]++; return nullptr; }
+        hipEvent_t* p = &ev[id][used[id]];
+        used[id] += 2;
+        return p;
+    }
+    void destroy() {
+        for (auto& v : ev) { for (auto& e : v) (void)hipEventDestroy(e); v.clear(); }
+    }
+};
+
+extern thread_local Profiler* tl_prof;   // set by the C-ABI entry points for the calling thread
+
+struct ProfScope {
+    hipEvent_t* e = nullptr;
+    hipStream_t s;
+    ProfScope(int id, hipStream_t stream) : s(stream) {
+        if (tl_prof && tl_prof->enabled) { e = tl_prof->next(id); if (e) (void)hipEventRecord(e[0], s); }
+    }
+    ~ProfScope() { if (e) (void)hipEventRecord(e[1], s); }
+};
+
+}  // namespace pmv

@@ -5,8 +5,9 @@
 // PARITY UNPINNED (OpenCV internals; published algorithm): Nistér five-point solver inside
 // RANSACPointSetRegistrator (RNG((uint64)-1), 5-point samples, <=1000 iterations, Sampson error, threshold 1px/mean focal),
 // degree-10 polynomial rooted by the Durand–Kerner iteration of cv::solvePoly, four-fold (R,t) cheirality test with DLT
-// triangulation.  FIXED CHOICES: null spaces via cyclic-Jacobi eigenvectors of A^T A; the 10x20 constraint matrix is built
-// by explicit polynomial algebra in Nistér's monomial order instead of OpenCV's generated coefficient table.
+// triangulation.  FIXED CHOICES: the 5x9 null space by Gauss–Jordan elimination (any basis of it gives the same E set), other
+// null vectors via cyclic-Jacobi eigenvectors of A^T A; the 10x20 constraint matrix is built by explicit polynomial algebra in
+// Nistér's monomial order instead of OpenCV's generated coefficient table; Durand–Kerner stops at 1e-14 relative movement.
 #include "vo_pipeline.h"
 #include "vo_math.h"
 #include <cfloat>
@@ -21,33 +22,42 @@ struct RNG {   // cv::RNG (multiply-with-carry)
     int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
 };
 
-// ---- polynomials in (x,y,z), total degree <= 3 ------------------------------------------------------------
-// index of monomial x^i y^j z^k
-inline int midx(int i, int j, int k) { return (i * 4 + j) * 4 + k; }
-struct Poly { double c[64]; Poly() { for (double& v : c) v = 0; } };
-inline Poly pmul(const Poly& a, const Poly& b) {
-    Poly r;
-    for (int i1 = 0; i1 < 4; i1++) for (int j1 = 0; j1 + i1 < 4; j1++) for (int k1 = 0; k1 + j1 + i1 < 4; k1++) {
-        const double av = a.c[midx(i1, j1, k1)];
-        if (av == 0.0) continue;
-        for (int i2 = 0; i2 + i1 < 4; i2++) for (int j2 = 0; j2 + j1 < 4; j2++) for (int k2 = 0; k2 + k1 < 4; k2++) {
-            if (i1 + j1 + k1 + i2 + j2 + k2 > 3) continue;
-            const double bv = b.c[midx(i2, j2, k2)];
-            if (bv == 0.0) continue;
-            r.c[midx(i1 + i2, j1 + j2, k1 + k2)] += av * bv;
-        }
-    }
-    return r;
-}
-inline Poly padd(const Poly& a, const Poly& b, double sb = 1.0) {
-    Poly r;
-    for (int i = 0; i < 64; i++) r.c[i] = a.c[i] + sb * b.c[i];
-    return r;
-}
-
+// ---- polynomials in (x,y,z): degree 1 (4 coefficients), degree 2 (10), degree 3 (20, Nistér's column order) ----------
 // Nistér's column order: x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1
-const int MONO[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
-                         {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+const int MONO3[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
+                          {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+const int MONO2[10][3] = {{2, 0, 0}, {0, 2, 0}, {0, 0, 2}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+const int MONO1[4][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+struct PolyTables {
+    int t11[4][4];    // degree-1 x degree-1 -> index into MONO2
+    int t21[10][4];   // degree-2 x degree-1 -> index into MONO3
+    PolyTables() {
+        for (int a = 0; a < 4; a++)
+            for (int b = 0; b < 4; b++) {
+                const int e[3] = {MONO1[a][0] + MONO1[b][0], MONO1[a][1] + MONO1[b][1], MONO1[a][2] + MONO1[b][2]};
+                for (int k = 0; k < 10; k++) if (MONO2[k][0] == e[0] && MONO2[k][1] == e[1] && MONO2[k][2] == e[2]) t11[a][b] = k;
+            }
+        for (int a = 0; a < 10; a++)
+            for (int b = 0; b < 4; b++) {
+                const int e[3] = {MONO2[a][0] + MONO1[b][0], MONO2[a][1] + MONO1[b][1], MONO2[a][2] + MONO1[b][2]};
+                for (int k = 0; k < 20; k++) if (MONO3[k][0] == e[0] && MONO3[k][1] == e[1] && MONO3[k][2] == e[2]) t21[a][b] = k;
+            }
+    }
+};
+const PolyTables& ptab() { static const PolyTables t; return t; }
+struct P1 { double c[4]; };
+struct P2 { double c[10]; P2() { for (double& v : c) v = 0; } };
+struct P3 { double c[20]; P3() { for (double& v : c) v = 0; } };
+inline void mac11(P2& r, const P1& a, const P1& b, double s = 1.0) {   // r += s * a * b
+    const PolyTables& T = ptab();
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) r.c[T.t11[i][j]] += s * (a.c[i] * b.c[j]);
+}
+inline void mac21(P3& r, const P2& a, const P1& b, double s = 1.0) {   // r += s * a * b
+    const PolyTables& T = ptab();
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 4; j++) r.c[T.t21[i][j]] += s * (a.c[i] * b.c[j]);
+}
 
 // cv::solvePoly (Durand–Kerner), coeffs ascending, degree n; returns roots (re, im)
 void solve_poly(const double* coeffs_in, int n0, std::vector<std::pair<double, double>>& roots_out) {
@@ -78,7 +88,11 @@ void solve_poly(const double* coeffs_in, int n0, std::vector<std::pair<double, d
             roots[i] = Cx{p.re - num.re, p.im - num.im};
             maxDiff = std::max(maxDiff, std::sqrt(num.re * num.re + num.im * num.im));
         }
-        if (maxDiff <= 0) break;
+        // cv::solvePoly stops only at maxDiff <= 0 (or after 300 sweeps); the iteration has converged to working precision
+        // long before (FIXED CHOICE: stop once no root moved by more than 1e-14 of its magnitude)
+        double scale = 0;
+        for (int i = 0; i < n; i++) scale = std::max(scale, std::fabs(roots[i].re) + std::fabs(roots[i].im));
+        if (maxDiff <= 1e-14 * (scale > 1.0 ? scale : 1.0)) break;
     }
     roots_out.clear();
     for (int i = 0; i < n; i++) {
@@ -89,60 +103,74 @@ void solve_poly(const double* coeffs_in, int n0, std::vector<std::pair<double, d
 
 // EMEstimatorCallback::runKernel: five normalised correspondences -> up to 10 essential matrices (row-major 3x3 each)
 int five_point_kernel(const double* q1, const double* q2, double* E_out) {
-    double QtQ[81];
     double Q[5][9];
     for (int i = 0; i < 5; i++) {
         const double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
         Q[i][0] = x1 * x2; Q[i][1] = y1 * x2; Q[i][2] = x2; Q[i][3] = x1 * y2; Q[i][4] = y1 * y2; Q[i][5] = y2; Q[i][6] = x1; Q[i][7] = y1; Q[i][8] = 1.0;
     }
-    for (int a = 0; a < 9; a++)
-        for (int b = 0; b < 9; b++) {
-            double acc = 0;
-            for (int i = 0; i < 5; i++) acc += Q[i][a] * Q[i][b];
-            QtQ[a * 9 + b] = acc;
+    // Null space of the 5x9 system. OpenCV takes the last four right singular vectors; the solution set {E} only depends
+    // on the 4-dimensional null SPACE, not on its basis, so (FIXED CHOICE) the basis comes from Gauss–Jordan elimination with
+    // full pivoting: x_free = e_k, x_pivot = -B[:, k].
+    int colperm[9];
+    for (int c = 0; c < 9; c++) colperm[c] = c;
+    for (int r = 0; r < 5; r++) {
+        int pr = r, pc = r;
+        double best = -1;
+        for (int i = r; i < 5; i++)
+            for (int j = r; j < 9; j++) if (std::fabs(Q[i][j]) > best) { best = std::fabs(Q[i][j]); pr = i; pc = j; }
+        if (!(best > 1e-300)) return 0;   // rank-deficient sample
+        if (pr != r) for (int j = 0; j < 9; j++) std::swap(Q[r][j], Q[pr][j]);
+        if (pc != r) { for (int i = 0; i < 5; i++) std::swap(Q[i][r], Q[i][pc]); std::swap(colperm[r], colperm[pc]); }
+        const double inv = 1.0 / Q[r][r];
+        for (int j = 0; j < 9; j++) Q[r][j] *= inv;
+        for (int i = 0; i < 5; i++) {
+            if (i == r) continue;
+            const double f = Q[i][r];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 9; j++) Q[i][j] -= f * Q[r][j];
         }
-    double w[9], V[81];
-    vmath::jacobi_eig(QtQ, 9, w, V);
-    // EE columns 0..3 <- right singular vectors 5..8 (descending order) = eigenvectors 3,2,1,0 (ascending order)
-    double EE[4][9];
-    for (int c = 0; c < 4; c++)
-        for (int k = 0; k < 9; k++) EE[c][k] = V[k * 9 + (3 - c)];
-    // E(x,y,z) = x EE0 + y EE1 + z EE2 + EE3 as 9 linear polynomials
-    Poly Ep[9];
-    for (int k = 0; k < 9; k++) {
-        Ep[k].c[midx(1, 0, 0)] = EE[0][k]; Ep[k].c[midx(0, 1, 0)] = EE[1][k]; Ep[k].c[midx(0, 0, 1)] = EE[2][k]; Ep[k].c[midx(0, 0, 0)] = EE[3][k];
     }
-    auto P = [&](int r, int c) -> const Poly& { return Ep[r * 3 + c]; };
-    std::vector<Poly> eqs;
+    double EE[4][9];
+    for (int k = 0; k < 4; k++) {
+        double v[9];
+        for (int j = 0; j < 9; j++) v[j] = 0;
+        for (int i = 0; i < 5; i++) v[i] = -Q[i][5 + k];
+        v[5 + k] = 1.0;
+        double nrm = 0;
+        for (int j = 0; j < 9; j++) nrm += v[j] * v[j];
+        nrm = std::sqrt(nrm);
+        for (int j = 0; j < 9; j++) EE[k][colperm[j]] = v[j] / nrm;
+    }
+    // E(x,y,z) = x EE0 + y EE1 + z EE2 + EE3 as 9 linear polynomials
+    P1 Ep[9];
+    for (int k = 0; k < 9; k++) { Ep[k].c[0] = EE[0][k]; Ep[k].c[1] = EE[1][k]; Ep[k].c[2] = EE[2][k]; Ep[k].c[3] = EE[3][k]; }
+    auto P = [&](int r, int c) -> const P1& { return Ep[r * 3 + c]; };
+    P3 eqs[10];
     // det(E) = 0
     {
-        Poly d = pmul(P(0, 0), padd(pmul(P(1, 1), P(2, 2)), pmul(P(1, 2), P(2, 1)), -1.0));
-        d = padd(d, pmul(P(0, 1), padd(pmul(P(1, 0), P(2, 2)), pmul(P(1, 2), P(2, 0)), -1.0)), -1.0);
-        d = padd(d, pmul(P(0, 2), padd(pmul(P(1, 0), P(2, 1)), pmul(P(1, 1), P(2, 0)), -1.0)));
-        eqs.push_back(d);
+        P2 m0, m1, m2;
+        mac11(m0, P(1, 1), P(2, 2)); mac11(m0, P(1, 2), P(2, 1), -1.0);
+        mac11(m1, P(1, 0), P(2, 2)); mac11(m1, P(1, 2), P(2, 0), -1.0);
+        mac11(m2, P(1, 0), P(2, 1)); mac11(m2, P(1, 1), P(2, 0), -1.0);
+        mac21(eqs[0], m0, P(0, 0)); mac21(eqs[0], m1, P(0, 1), -1.0); mac21(eqs[0], m2, P(0, 2));
     }
     // 2 E E^T E - trace(E E^T) E = 0
     {
-        Poly EEt[9], tr;
+        P2 EEt[9], tr;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                for (int k = 0; k < 3; k++) mac11(EEt[i * 3 + j], P(i, k), P(j, k));
+        for (int k = 0; k < 10; k++) tr.c[k] = EEt[0].c[k] + EEt[4].c[k] + EEt[8].c[k];
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) {
-                Poly s;
-                for (int k = 0; k < 3; k++) s = padd(s, pmul(P(i, k), P(j, k)));
-                EEt[i * 3 + j] = s;
-            }
-        tr = padd(padd(EEt[0], EEt[4]), EEt[8]);
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-                Poly s;
-                for (int k = 0; k < 3; k++) s = padd(s, pmul(EEt[i * 3 + k], P(k, j)));
-                Poly e = padd(s, s);                       // 2 (E E^T E)_ij
-                e = padd(e, pmul(tr, P(i, j)), -1.0);
-                eqs.push_back(e);
+                P3& e = eqs[1 + i * 3 + j];
+                for (int k = 0; k < 3; k++) mac21(e, EEt[i * 3 + k], P(k, j), 2.0);
+                mac21(e, tr, P(i, j), -1.0);
             }
     }
     double A[10][20];
     for (int r = 0; r < 10; r++)
-        for (int c = 0; c < 20; c++) A[r][c] = eqs[r].c[midx(MONO[c][0], MONO[c][1], MONO[c][2])];
+        for (int c = 0; c < 20; c++) A[r][c] = eqs[r].c[c];
     // A <- A[:, :10]^-1 A[:, 10:]  (Gauss–Jordan with partial pivoting)
     for (int c = 0; c < 10; c++) {
         int piv = c;
@@ -415,6 +443,7 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
             f3d->id = tracker->next_landmark_id++;
             f3d->transform(tracker->R[j], tracker->t[j]);
             tracker->feats3d.push_back(f3d);
+            f3d->self = std::prev(tracker->feats3d.end());
             next.map[p2_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
             src.map[p1_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
         }

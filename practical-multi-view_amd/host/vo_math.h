@@ -15,6 +15,10 @@ namespace vmath {
 inline void jacobi_eig(double* A, int n, double* w, double* V, int max_sweeps = 30) {
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    // off-diagonals below 1e-17 * trace are noise (they would only rotate rounding errors inside null spaces for ever)
+    double tol_abs = 0;
+    for (int i = 0; i < n; i++) tol_abs += std::fabs(A[i * n + i]);
+    tol_abs *= 1e-17;
     for (int sweep = 0; sweep < max_sweeps; sweep++) {
         int rotated = 0;
         for (int p = 0; p < n - 1; p++)
@@ -22,8 +26,7 @@ inline void jacobi_eig(double* A, int n, double* w, double* V, int max_sweeps = 
                 const double apq = A[p * n + q];
                 if (apq == 0.0) continue;
                 const double app = A[p * n + p], aqq = A[q * n + q];
-                // skip rotations that cannot change the diagonal in double precision
-                if (std::fabs(apq) <= 1e-18 * (std::fabs(app) + std::fabs(aqq)) ) { A[p * n + q] = A[q * n + p] = 0.0; continue; }
+                if (std::fabs(apq) <= tol_abs) { A[p * n + q] = A[q * n + p] = 0.0; continue; }
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
                 const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;

@@ -125,7 +125,11 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
     std::vector<int> inliers;
     const int m = (int)(obj_points.size() / 3);
     tracker->stats.pnp_calls++; tracker->stats.pnp_points += m;
-    pnp_ransac(obj_points.data(), img_points.data(), m, tracker->camera, _R_rod, t_out.v, inliers);
+    {
+        const auto k0 = std::chrono::steady_clock::now();
+        pnp_ransac(obj_points.data(), img_points.data(), m, tracker->camera, _R_rod, t_out.v, inliers);
+        tracker->stats.t_pnp_kernel += std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count();
+    }
     rodrigues_v2m(_R_rod, R_out.m);
     // Removing RANSAC outliers (:40-49)
     std::vector<uint8_t> is_inlier(m, 0);
@@ -134,8 +138,7 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
         if (!is_inlier[i]) {
             if (local_feats3d[i].expired()) continue;
             std::shared_ptr<Feature3D> f3d = local_feats3d[i].lock();
-            auto it = std::find(tracker->feats3d.begin(), tracker->feats3d.end(), f3d);
-            tracker->feats3d.erase(it);
+            tracker->feats3d.erase(f3d->self);
         }
     }
 }
@@ -190,9 +193,12 @@ void BundleAdjustmentBase::apply(Frame& f) {
         for (int& c : obs_cam) c = remap[c];
     }
     tracker->stats.ba_calls++; tracker->stats.ba_obs += n_obs; tracker->stats.ba_points += (long)p3d_ptr.size();
-    if (n_obs > 0)
+    if (n_obs > 0) {
+        const auto k0 = std::chrono::steady_clock::now();
         ba_solve(cams_c.data(), nc, p3d_opt.data(), (int)p3d_ptr.size(), obs.data(), obs_cam.data(), obs_pt.data(), n_obs,
                  tracker->camera, 1.0, tracker->cfg.ba_iterations);
+        tracker->stats.t_ba_kernel += std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count();
+    }
     for (size_t c = 0; c < cam_frame.size(); c++)
         if (remap[c] >= 0) for (int k = 0; k < 6; k++) tr_opt[c * 6 + k] = cams_c[remap[c] * 6 + k];
     // Updating 3D points and camera poses (:67-88)
@@ -271,7 +277,9 @@ void OdometryPipeline::initialise() {   // :428-482
 
 void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
     frame.frame = (int)frames.size();
+    const auto tl0 = std::chrono::steady_clock::now();
     fmap feat_corr = matcher->matchFeatures(*(frames[frame.frame - 1]), frame);
+    stats.t_lk += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
     stats.lk_calls++; stats.lk_points += (long)frames[frame.frame - 1]->map.size();
     frames[frame.frame - 1]->feat_corr = feat_corr;
     if ((int)feat_corr.size() < cfg.tracked_features_tol) {
@@ -279,7 +287,9 @@ void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
         const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
         std::vector<Frame> cells;
         for (auto& r : roi) cells.push_back(r.frame);
+        const auto td0 = std::chrono::steady_clock::now();
         std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
+        stats.t_detect += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
         stats.detect_calls++;
         for (size_t k = 0; k < roi.size(); k++)
             for (auto& f : all[k]) {
@@ -315,15 +325,24 @@ void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
     const int j = src.frame;
     Mat3 _R = R[j];
     Vec3 _t = t[j];
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+    const auto t0 = tnow();
     if (src.count3DPoints() >= cfg.tracked_features_tol) {
         pnpsolver->solvePnP(src, next, _R, _t);
+        stats.t_pnp += secs(t0);
     } else {
         triangulator->triangulate(src, next, _R, _t);
         stats.tri_calls++;
+        stats.t_tri += secs(t0);
     }
     motionHeuristics(_R, _t, j);
     // (frames[src.frame], frames[next.frame] are updated in place; the reference works on copies and writes them back)
-    if (cfg.bundle_size && src.frame && src.frame % (cfg.bundle_size / 3 * 2) == 0) ba->apply(next);
+    if (cfg.bundle_size && src.frame && src.frame % (cfg.bundle_size / 3 * 2) == 0) {
+        const auto t1 = tnow();
+        ba->apply(next);
+        stats.t_ba += secs(t1);
+    }
 }
 
 void OdometryPipeline::run() {   // startPipeline :247-264 + featureExtractionThread :212-229 + poseEstimationThread :237-243
@@ -380,7 +399,9 @@ void OdometryPipeline::run_threaded() {
         }
         std::shared_ptr<Frame> prev;
         { std::unique_lock<std::mutex> lk(mu); prev = frames[frame.frame - 1]; }
+        const auto tl0 = std::chrono::steady_clock::now();
         fmap feat_corr = matcher->matchFeatures(*prev, frame);
+        stats.t_lk += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
         stats.lk_calls++; stats.lk_points += (long)prev->map.size();
         prev->feat_corr = feat_corr;
         if ((int)feat_corr.size() < cfg.tracked_features_tol) {
@@ -388,7 +409,9 @@ void OdometryPipeline::run_threaded() {
             const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
             std::vector<Frame> cells;
             for (auto& r : roi) cells.push_back(r.frame);
+            const auto td0 = std::chrono::steady_clock::now();
             std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
+            stats.t_detect += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
             stats.detect_calls++;
             for (size_t k = 0; k < roi.size(); k++)
                 for (auto& f : all[k])

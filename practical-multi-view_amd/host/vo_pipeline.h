@@ -8,6 +8,8 @@
 #pragma once
 #include "vo_types.h"
 #include <functional>
+#include <chrono>
+#include <list>
 
 namespace vo {
 
@@ -76,6 +78,8 @@ public:
 struct Stats {
     long lk_calls = 0, lk_points = 0, detect_calls = 0, pnp_calls = 0, pnp_points = 0, tri_calls = 0, ba_calls = 0, ba_obs = 0, ba_points = 0;
     long heuristic_motion = 0;
+    // wall time per stage as seen by the calling host thread (adapter gather/scatter + plugin kernel + sync)
+    double t_lk = 0, t_detect = 0, t_pnp = 0, t_tri = 0, t_ba = 0, t_pnp_kernel = 0, t_ba_kernel = 0;
 };
 
 class OdometryPipeline {
@@ -86,7 +90,9 @@ public:
     double camera[9];                       // row-major 3x3
     std::vector<ImageView> images;          // the sequence ("file_names"): decoded gray frames
     std::vector<Vec3> gt_t;                 // ground-truth positions (parsePoses), used for scale only (Q11)
-    std::vector<std::shared_ptr<Feature3D>> feats3d;
+    // the reference keeps a std::vector and erases RANSAC outliers with std::find + erase (O(N) each, OpenCVEPnPSolver.cpp:47);
+    // a std::list with the node iterator stored in the landmark has the same content/order semantics at O(1) per erase
+    std::list<std::shared_ptr<Feature3D>> feats3d;
     std::vector<std::shared_ptr<Frame>> frames;
     std::vector<Mat3> R, R_s;
     std::vector<Vec3> t, t_s;

@@ -12,6 +12,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <list>
 
 namespace vo {
 
@@ -89,6 +90,7 @@ class Feature3D {
 public:
     float x, y, z;
     int id = -1;   // creation order (explicit landmark id); not used by any arithmetic
+    std::list<std::shared_ptr<Feature3D>>::iterator self;   // position in OdometryPipeline::feats3d (O(1) erase)
     Feature3D(double x_, double y_, double z_) : x((float)x_), y((float)y_), z((float)z_) {}
     void rotate(const Mat3& R) {   // Feature3D.cpp:125-139
         double x0 = R.m[0] * x + R.m[1] * y + R.m[2] * z;

@@ -107,10 +107,11 @@ class PipelineResult:
             if c:
                 g("get_frame_features")(handle, k, _p(a, _i32p))
             self.features.append(a)
-        st = np.zeros(16, np.float64)
+        st = np.zeros(24, np.float64)
         g("get_stats")(handle, _p(st, _f64p))
         keys = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
-                "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale"]
+                "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale", "t_lk", "t_detect", "t_pnp", "t_tri",
+             "t_ba", "t_pnp_kernel", "t_ba_kernel"]
         self.stats = dict(zip(keys, st[:len(keys)]))
 
 
