@@ -92,3 +92,71 @@ int orc_pipeline_frame_feature_count(void* h, int k) { return vo::pipeline_frame
 void orc_pipeline_get_frame_features(void* h, int k, int* out) { vo::pipeline_get_frame_features(*(vo::PipelineRun*)h, k, out); }
 void orc_pipeline_get_stats(void* h, double* out16) { vo::pipeline_get_stats(*(vo::PipelineRun*)h, out16); }
 }
+
+// ---- host-logic probes for the CPU test-suite (KA5/KA6/KA9/KA10 of SURVEY.md §8c) ------------------------------------------
+extern "C" {
+uint64_t orc_host_coord_hash(int v) { return (uint64_t)vo::coord_hash(v); }
+// getGridROI: returns the number of cells; out: (x0, y0, w, h, gx, gy) per cell
+int orc_host_grid(int w, int h, int* out) {
+    vo::OdometryPipeline pl;
+    vo::ImageView v; v.full_w = w; v.full_h = h; v.w = w; v.h = h;
+    vo::Frame fr(v);
+    auto roi = pl.getGridROI(fr);
+    for (size_t i = 0; i < roi.size(); i++) {
+        out[6 * i] = roi[i].frame.bw.x0; out[6 * i + 1] = roi[i].frame.bw.y0; out[6 * i + 2] = roi[i].frame.bw.w; out[6 * i + 3] = roi[i].frame.bw.h;
+        out[6 * i + 4] = roi[i].x; out[6 * i + 5] = roi[i].y;
+    }
+    return (int)roi.size();
+}
+double orc_host_stddev(const double* v, int n) { return vo::OdometryPipeline::standardDeviation(std::vector<double>(v, v + n)); }
+double orc_host_yrot(const double* R9, int flip) { vo::Mat3 R; memcpy(R.m, R9, 72); return vo::OdometryPipeline::calcYRotation(R, flip != 0); }
+// insert n features (col,row) into a Frame::map in the given order; out = iteration order as indices into the input
+void orc_host_map_order(const int* cols, const int* rows, int n, int* out) {
+    vo::Frame fr;
+    std::vector<std::shared_ptr<vo::Feature>> keep;
+    std::unordered_map<vo::Feature*, int> idx;
+    for (int i = 0; i < n; i++) {
+        auto f = std::make_shared<vo::Feature>(cols[i], rows[i]);
+        keep.push_back(f); idx[f.get()] = i;
+        fr.map[f] = std::weak_ptr<vo::Feature3D>();
+    }
+    int k = 0;
+    for (auto& p : fr.map) out[k++] = idx[p.first.get()];
+}
+// feat_corr semantics: keys compare by coordinates (same-pixel sources collapse, last value wins). Returns the number of
+// entries; out_key / out_val = indices of the surviving key feature and of its value, in iteration order
+int orc_host_corr_order(const int* cols, const int* rows, int n, int* out_key, int* out_val) {
+    vo::fmap corr;
+    std::vector<std::shared_ptr<vo::Feature>> src, dst;
+    std::unordered_map<vo::Feature*, int> si, di;
+    for (int i = 0; i < n; i++) {
+        auto a = std::make_shared<vo::Feature>(cols[i], rows[i]);
+        auto b = std::make_shared<vo::Feature>(cols[i] + 1000, rows[i] + 1000);
+        src.push_back(a); dst.push_back(b); si[a.get()] = i; di[b.get()] = i;
+        corr[a] = b;
+    }
+    int k = 0;
+    for (auto& p : corr) { out_key[k] = si[p.first.lock().get()]; out_val[k] = di[p.second.lock().get()]; k++; }
+    return k;
+}
+// OdometryPipeline.cpp:407 trigger and CeresBundleAdjustment.cpp:7-8,20-23 window for estimatePose(src_frame, src_frame+1)
+int orc_host_ba_schedule(int bundle_size, int src_frame, int* win_first, int* win_count) {
+    const int trig = bundle_size && src_frame && src_frame % (bundle_size / 3 * 2) == 0;
+    const int fn = src_frame + 1 + 1, n = std::min(bundle_size, fn);
+    int cnt = 0, first = -1;
+    for (int i = fn - n; i < fn; i++) { if (i == 0) continue; if (first < 0) first = i; cnt++; }
+    *win_first = first; *win_count = cnt;
+    return trig;
+}
+void orc_host_project_point(const double* R, const double* t, const double* camera, const double* p3, double* p2) {
+    vo::Feature3D::projectPoint(R, t, camera, p3, p2);
+}
+// Feature3D::transform / transformInv on a float32 point (quirk Q7)
+void orc_host_f3d_roundtrip(const double* R9, const double* t3, float* xyz, int inverse_first) {
+    vo::Mat3 R; memcpy(R.m, R9, 72);
+    vo::Vec3 t{{t3[0], t3[1], t3[2]}};
+    vo::Feature3D f(xyz[0], xyz[1], xyz[2]);
+    if (inverse_first) { f.transformInv(R, t); f.transform(R, t); } else { f.transform(R, t); f.transformInv(R, t); }
+    xyz[0] = f.x; xyz[1] = f.y; xyz[2] = f.z;
+}
+}

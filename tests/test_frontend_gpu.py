@@ -171,3 +171,25 @@ def test_error_paths(pmv, gpu_ctx_factory):
         ctx.lk_track(0, 0, np.zeros((9, 2), np.float32))             # exceeds max_tracks
     with pytest.raises(pmv.PmvError):
         ctx.detect_gftt(0, np.asarray([[0, 0, 256, 50]], np.int32), 10)   # cell wider than 255
+
+
+def test_committed_golden_vectors(pmv, gpu_ctx_factory):
+    """tests/golden/frontend_640x200.npz (made by tests/golden/make_fixtures.py with the oracle): corner lists, LK positions,
+    status and error must be reproduced bit for bit from the regenerated seeded frames."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_640x200.npz"))
+    w, h, f = int(g["w"]), int(g["h"]), float(g["f"])
+    frames, _ = pmv.synth_sequence(int(g["seed"]), int(g["first"]), 2, w, h, f, f, 320.0, 100.0, nthreads=4)
+    ctx = gpu_ctx_factory(w, h, n_slots=2)
+    ctx.frame_upload(0, frames[0])
+    ctx.frame_upload(1, frames[1])
+    cells = pmv.grid_cells(w, h)
+    det = ctx.detect_gftt(0, cells, 20)
+    assert [len(d) for d in det] == list(g["corner_counts"])
+    assert np.array_equal(np.concatenate(det), g["corners"].astype(np.int32))
+    pts = np.concatenate([d + c[:2] for c, d in zip(cells, det)]).astype(np.float32)
+    xy, st, err = ctx.lk_track(0, 1, pts)
+    assert ctx.num_levels(0) == int(g["levels"])
+    assert np.array_equal(st, g["lk_status"])
+    ok = st > 0
+    assert np.array_equal(xy[ok], g["lk_xy"][ok]) and np.array_equal(err[ok], g["lk_err"][ok])

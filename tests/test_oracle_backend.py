@@ -1,0 +1,159 @@
+"""Oracle back-end: ProjectionResidual/Jacobians (pinned by in-repo source), Rodrigues, cv::RNG stream, RANSAC/EPnP, the LM
+bundle adjustment and the five-point triangulator — against numpy/scipy twins, finite differences and exact synthetic scenes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc_binding as ob
+import scenes
+
+_f64p = C.POINTER(C.c_double)
+
+
+def _P(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def test_projection_residual_matches_reference_formula_and_projectpoint_twin(orc):
+    """KA1: ProjectionResidual (ProjectionResidual.h:38-58) with tr = [aa(R^T), -t] equals Feature3D::projectPoint(R, t)
+    (Feature3D.cpp:18-33) for the same pixel; both equal the numpy twin."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        R = Rotation.from_rotvec(rng.normal(0, 0.3, 3)).as_matrix()
+        t = rng.normal(0, 1, 3)
+        X = np.array([rng.uniform(-5, 5), rng.uniform(-2, 2), rng.uniform(-30, -6)]) + t
+        cam = np.concatenate([Rotation.from_matrix(R.T).as_rotvec(), -t])
+        obs = np.zeros(2)
+        r, J = ob.ba_residuals(cam[None], X[None], obs[None], [0], [0], scenes.K)
+        proj = -r[0]
+        np.testing.assert_allclose(proj, scenes.project_ref(cam, X), rtol=1e-12, atol=1e-9)
+        p2 = np.zeros(2)
+        orc.lib.orc_host_project_point(_P(np.ascontiguousarray(R).reshape(9)), _P(t), _P(scenes.K), _P(X), _P(p2))
+        np.testing.assert_allclose(proj, p2, rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("aa", [[0.02, -0.3, 0.01], [1e-9, 2e-9, -1e-9], [0, 0, 0], [2.5, 0.3, -1.0]])
+def test_analytic_jacobian_matches_finite_differences(aa):
+    """KA3: both AngleAxisRotatePoint branches (theta^2 > eps and the first-order one)."""
+    rng = np.random.default_rng(0)
+    cam = np.concatenate([aa, rng.normal(0, 1, 3)])
+    X = np.array([1.0, -0.5, -12.0]) + rng.normal(0, 1, 3)
+    obs = np.array([500.0, 200.0])
+    r, J = ob.ba_residuals(cam[None], X[None], obs[None], [0], [0], scenes.K)
+    num = np.zeros((2, 9))
+    h = 1e-6
+    for k in range(9):
+        c2, X2, c3, X3 = cam.copy(), X.copy(), cam.copy(), X.copy()
+        if k < 6:
+            c2[k] += h; c3[k] -= h
+        else:
+            X2[k - 6] += h; X3[k - 6] -= h
+        num[:, k] = ((obs - scenes.project_ref(c2, X2)) - (obs - scenes.project_ref(c3, X3))) / (2 * h)
+    np.testing.assert_allclose(J[0], num, rtol=2e-6, atol=2e-6 * np.abs(num).max())
+
+
+def test_rodrigues_matches_scipy_and_opencv_special_cases():
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        r = rng.normal(0, 1.0, 3)
+        R = ob.rodrigues_v2m(r)
+        np.testing.assert_allclose(R, Rotation.from_rotvec(r).as_matrix(), atol=1e-14)
+        np.testing.assert_allclose(ob.rodrigues_m2v(R), Rotation.from_matrix(R).as_rotvec(), atol=1e-10)
+    assert np.array_equal(ob.rodrigues_v2m(np.zeros(3)), np.eye(3))
+    assert np.array_equal(ob.rodrigues_m2v(np.eye(3)), np.zeros(3))          # s < 1e-5, c > 0 -> zero vector
+    np.testing.assert_allclose(np.abs(ob.rodrigues_m2v(np.diag([1.0, -1.0, -1.0]))), [np.pi, 0, 0], atol=1e-12)   # theta = pi branch
+    # non-orthonormal input is projected by the SVD step first
+    R = Rotation.from_rotvec([0.2, -0.1, 0.4]).as_matrix()
+    np.testing.assert_allclose(ob.rodrigues_m2v(R * 1.0000001), Rotation.from_matrix(R).as_rotvec(), atol=1e-7)
+
+
+def test_cv_rng_stream_golden(orc):
+    """cv::RNG: state = (u32)state * 4164903690 + (state >> 32), seeded with (uint64)-1; uniform(a,b) = a + next() % (b-a)."""
+    state = 2 ** 64 - 1
+    want = []
+    for _ in range(16):
+        state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & (2 ** 64 - 1)
+        want.append((state & 0xFFFFFFFF) % 400)
+    got = np.zeros(16, np.int32)
+    orc.lib.orc_rng_sequence(C.c_uint64(2 ** 64 - 1), 16, 400, got.ctypes.data_as(C.POINTER(C.c_int)))
+    assert list(got) == want
+    assert want[:4] == [5, 204, 140, 373]     # golden (also the first RANSAC sample of a 400-point problem)
+
+
+@pytest.mark.parametrize("seed,m,frac", [(1, 400, 0.2), (2, 150, 0.1), (3, 549, 0.35), (5, 60, 0.0)])
+def test_pnp_ransac_recovers_pose_and_rejects_outliers(seed, m, frac):
+    P = scenes.pnp_problem(seed, m=m, outlier_frac=frac)
+    rv, tv, inl, hyp = ob.pnp_ransac(P["obj"], P["img"], scenes.K, [0.3, -0.2, 0.1], [1.0, 2.0, -30.0])
+    assert np.abs(rv - P["rvec_true"]).max() < 5e-3 and np.abs(tv - P["tvec_true"]).max() < 5e-2
+    assert P["outliers"][inl].mean() < 0.05
+    assert len(inl) >= 0.9 * (~P["outliers"]).sum()
+    assert 1 <= hyp <= 100
+    if frac == 0.0:
+        assert hyp <= 3          # RANSACUpdateNumIters cuts the loop as soon as (almost) everything is an inlier
+
+
+def test_pnp_exact_data_gives_exact_pose():
+    """KA8: noiseless correspondences -> pose to float32-input precision."""
+    P = scenes.pnp_problem(7, m=200, outlier_frac=0.0, noise=0.0)
+    # undo the floor() of the scene builder: project exactly
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_rotvec(P["rvec_true"]).as_matrix()
+    Xc = (R @ P["obj"].astype(np.float64).T).T + P["tvec_true"]
+    K = scenes.K
+    uv = np.stack([Xc[:, 0] / Xc[:, 2] * K[0] + K[2], Xc[:, 1] / Xc[:, 2] * K[4] + K[5]], 1).astype(np.float32)
+    rv, tv, inl, _ = ob.pnp_ransac(P["obj"], uv, K, np.zeros(3), np.zeros(3))
+    assert len(inl) == 200
+    assert np.abs(rv - P["rvec_true"]).max() < 1e-5 and np.abs(tv - P["tvec_true"]).max() < 2e-4
+
+
+def test_ba_reduces_cost_and_handles_outliers_with_huber():
+    P = scenes.ba_problem(1, nc=5, npts=300)
+    cams, pts, s = ob.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 5)
+    assert s["iterations"] == 5 and s["successful_steps"] >= 4
+    assert s["final_cost"] < 0.2 * s["initial_cost"]
+    # the initial cost is 1/2 sum rho(|r|^2) with Huber(1)
+    r, _ = ob.ba_residuals(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K)
+    sq = (r ** 2).sum(1)
+    rho = np.where(sq > 1, 2 * np.sqrt(sq) - 1, sq)
+    np.testing.assert_allclose(s["initial_cost"], 0.5 * rho.sum(), rtol=1e-12)
+
+
+def test_ba_noiseless_converges_and_zero_iterations_is_identity():
+    P = scenes.ba_problem(21, nc=5, npts=200, noise=0.0, outlier_every=0)
+    obs = np.array([scenes.project_ref(P["cams_true"][c], P["pts_true"][p]) for c, p in zip(P["cam_idx"], P["pt_idx"])])
+    cams, pts, s = ob.ba_solve(P["cams"], P["pts"], obs, P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 50)
+    assert s["final_cost"] < 1e-6 * s["initial_cost"]
+    c0, p0, s0 = ob.ba_solve(P["cams"], P["pts"], obs, P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 0)
+    assert np.array_equal(c0, P["cams"]) and np.array_equal(p0, P["pts"]) and s0["iterations"] == 0
+
+
+def test_ba_trigger_schedule_and_window(orc):
+    """KA9: OdometryPipeline.cpp:407 (integer arithmetic!) and CeresBundleAdjustment.cpp:7-8,20-23."""
+    wf, wc = C.c_int(), C.c_int()
+
+    def q(b, j):
+        trig = orc.lib.orc_host_ba_schedule(b, j, C.byref(wf), C.byref(wc))
+        return trig, wf.value, wc.value
+    for b, period in ((3, 2), (5, 2), (10, 6), (20, 12)):
+        trig = [j for j in range(0, 40) if q(b, j)[0]]
+        assert trig == [j for j in range(1, 40) if j % period == 0]
+    assert q(5, 2) == (1, 1, 3)        # next = frame 3: window frames {0..3} minus frame 0, n = min(5, 4)
+    assert q(5, 10) == (1, 7, 5)       # frames 7..11
+    assert q(3, 2) == (1, 1, 3)
+    assert q(10, 6) == (1, 1, 7)       # fn = 8 < bundle: frames 1..7
+    assert q(0, 4)[0] == 0
+
+
+def test_feature3d_float32_round_trip_quirk_q7(orc):
+    """KA2: transformInv o transform = id only up to float32 rounding (the reference does this round trip every frame)."""
+    from scipy.spatial.transform import Rotation
+    R = np.ascontiguousarray(Rotation.from_rotvec([0.01, -0.4, 0.02]).as_matrix()).reshape(9)
+    t = np.array([3.0, -0.2, -250.0])
+    p = np.array([4.1234567, -1.7654321, -263.123456], np.float32)
+    q = p.copy()
+    orc.lib.orc_host_f3d_roundtrip(_P(R), _P(t), q.ctypes.data_as(C.POINTER(C.c_float)), 1)
+    assert np.abs(q - p).max() < 1e-4 and q.dtype == np.float32
+    assert np.abs(q.astype(np.float64) - p).max() <= 64 * np.spacing(np.float32(263.0))
