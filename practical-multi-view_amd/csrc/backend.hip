@@ -43,7 +43,7 @@ int backend_create(pmv_ctx* c) {
     c->be = b;
     const size_t nc = (size_t)std::max(c->max_ba_cams, 1), np = (size_t)std::max(c->max_ba_points, 1), no = (size_t)std::max(c->max_ba_obs, 1);
     const size_t n = 6 * nc + 3 * np, m = 6 * nc;
-    const size_t ldw = (size_t)round_up((int)m + 1, 16), krows = (size_t)round_up((int)(3 * np), 4);
+    const size_t ldw = (size_t)round_up((int)m + 1, 16), krows = (size_t)round_up((int)(3 * np), 16);
 #define CKB(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(c, "%s: %s", #x, hipGetErrorString(e_)); return PMV_ERR_HIP; } } while (0)
     CKB(hipMalloc(&b->d_cams, nc * 6 * 8)); CKB(hipMalloc(&b->d_pts, np * 3 * 8)); CKB(hipMalloc(&b->d_obs, no * 2 * 8)); CKB(hipMalloc(&b->d_K, 9 * 8));
     CKB(hipMalloc(&b->d_cam_idx, no * 4)); CKB(hipMalloc(&b->d_pt_idx, no * 4));
@@ -280,15 +280,15 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     const int m = 6 * nc;
     A.tiles_r = (m + 15) / 16; A.tiles_c = (m + 1 + 15) / 16;
     A.ldw = A.tiles_c * 16;
-    A.krows = round_up(3 * np, 4);
+    A.krows = round_up(3 * np, 16);
     A.gp_rows = A.tiles_r * 16;
     int ks = 8 / (A.tiles_r * A.tiles_c);
     if (ks < 1) ks = 1;
     if (ks > 8) ks = 8;
-    A.kper = round_up((A.krows + ks - 1) / ks, 4);
+    A.kper = round_up((A.krows + ks - 1) / ks, 16);
     A.kslices = (A.krows + A.kper - 1) / A.kper;
     REQ((size_t)A.krows * A.ldw <= b->ydwd_elems && (size_t)A.kslices * A.gp_rows * A.ldw <= b->gpart_elems, PMV_ERR_CAPACITY, "pmv_ba_solve: workspace too small");
-    REQ(((size_t)m * m + 2 * (size_t)m + 27 * 128) * 8 <= 150 * 1024, PMV_ERR_CAPACITY, "pmv_ba_solve: %d cameras exceed the LDS-resident reduced system (max 20)", nc);
+    REQ(((size_t)(m + 1) * m + (size_t)m) * 8 <= 150 * 1024, PMV_ERR_CAPACITY, "pmv_ba_solve: %d cameras exceed the LDS-resident reduced system (max 22)", nc);
     CKC(launch_ba_lm(s, A));
     const size_t out_bytes = (8 + (size_t)nc * 6 + (size_t)np * 3) * 8;
     CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));

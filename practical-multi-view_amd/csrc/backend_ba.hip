@@ -231,34 +231,91 @@ __device__ inline void huber_rho(double s, double a, double& rho0, double& rho1)
 
 #define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// Camera blocks on FP64 MFMA: for camera c, F = the 2*n_c rows of its observations with columns [Jc(6) | r | 0...]; one
+// wavefront accumulates D = F^T F (16x16) over K = 2*n_c in steps of 4: D[a][b] (a,b<6) = U_c, D[a][6] = rhs_c.
+// The same value feeds the A and B operand of a lane (A[i=l&15][k=l>>4] = B[k=l>>4][j=l&15] = F[k][l&15]).
+__device__ inline v4d cam_block_mfma(const double* __restrict__ J, const double* __restrict__ res, const int* __restrict__ cobs_list,
+                                     int e0, int e1, int lane) {
+    v4d acc = {0, 0, 0, 0};
+    const int a = lane & 15, g = lane >> 4;
+    const int nrows = __builtin_amdgcn_readfirstlane(2 * (e1 - e0));
+    const bool act = a < 7;
+    for (int k0 = 0; k0 < nrows; k0 += 16) {   // 4 MFMA steps per batch: all index loads, then all value loads, then the MFMAs
+        int idx[4];
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = k0 + 4 * u + g;
+            idx[u] = (act && r < nrows) ? cobs_list[e0 + (r >> 1)] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = k0 + 4 * u + g;
+            v[u] = 0.0;
+            if (idx[u] >= 0) v[u] = (a < 6) ? J[(size_t)idx[u] * 18 + (r & 1) * 6 + a] : res[2 * idx[u] + (r & 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);
+    }
+    return acc;   // D[row = (lane>>4) + 4*reg][col = lane&15]
+}
+
 __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
     __shared__ double red[BA_NW];
-    __shared__ double cred[BA_NW * 27];
     __shared__ BAState st;
     __shared__ CamRot crot[32];
-    extern __shared__ __attribute__((aligned(16))) double dyn[];   // S (m*m) | rhs (m) | stepc (m): the reduced camera system
+    __shared__ double sdj;
+    extern __shared__ __attribute__((aligned(16))) double dyn[];   // M ((m+1) x m: S rows then the rhs row) | stepc (m)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nc = A.nc, np = A.np, nobs = A.nobs;
     const int n = 6 * nc + 3 * np, m = 6 * nc;
-    const int ldw = A.ldw;          // row stride of Yd / Wd (multiple of 16, >= m + 1)
-    const int krows = A.krows;      // 3*np padded to a multiple of 4
+    const int ldw = A.ldw;          // number of columns of Yt / Wt (multiple of 16, >= m + 1)
+    const int krows = A.krows;      // 3*np padded to a multiple of 16
     double* x = A.x; double* cand = A.cand; double* scale = A.scale; double* diag = A.diag; double* D2 = A.D2;
     double* step = A.step; double* res = A.res; double* J = A.J; double* Einv = A.Einv; double* gp = A.gp;
-    double* Yd = A.Yd; double* Wd = A.Wd; double* Gp = A.Gpart;
-    double* S = dyn; double* rhs = dyn + (size_t)m * m; double* stepc = rhs + m; double* ctile = stepc + m;   // ctile: 27 x CB_CH
+    double* Yt = A.Yd; double* Wt = A.Wd; double* Gp = A.Gpart;   // Yt/Wt are stored TRANSPOSED: [column][k]
+    double* S = dyn; double* rhs = dyn + (size_t)m * m; double* stepc = rhs + m;
 
     // diagnostic phase timers (shader clock), only when A.stamps != nullptr
     unsigned long long t_prev = 0;
 #define STAMP(k) do { if (A.stamps) { __syncthreads(); if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); A.stamps[k] += t_ - t_prev; t_prev = t_; } } } while (0)
     if (A.stamps && tid == 0) { t_prev = __builtin_readcyclecounter(); A.stamps[30] = wall_clock64(); A.stamps[31] = t_prev; }
-    // x <- [cams | pts]
+    // x <- [cams | pts]; zero the K padding rows of Yt / Wt once (they are never written again)
     for (int i = tid; i < 6 * nc; i += BA_T) x[i] = A.cams[i];
     for (int i = tid; i < 3 * np; i += BA_T) x[6 * nc + i] = A.pts[i];
+    {
+        const int padk = krows - 3 * np;
+        for (int i = tid; i < ldw * padk; i += BA_T) {
+            const int col = i / padk, k = 3 * np + (i - col * padk);
+            Yt[(size_t)col * krows + k] = 0.0; Wt[(size_t)col * krows + k] = 0.0;
+        }
+        for (int i = tid; i < (ldw - m) * 3 * np; i += BA_T) {   // Yt column m (pairs with g) and the unused tail columns
+            const int col = m + i / (3 * np), k = i % (3 * np);
+            Yt[(size_t)col * krows + k] = 0.0;
+            if (col > m) Wt[(size_t)col * krows + k] = 0.0;
+        }
+    }
     if (tid == 0) {
         st.radius = 1e4; st.decrease = 2.0; st.iter = 0; st.reuse_diag = 0; st.invalid = 0; st.need_eval = 1; st.done = 0;
         st.termination = 0; st.successful = 0; st.chol_fail = 0; st.first = 1; st.gmax = 0; st.x_cost = 0;
     }
     __syncthreads();
+
+    // camera blocks (all cameras, waves in parallel) into S / rhs; S must have been zeroed
+    auto camera_blocks = [&]() {
+        for (int c = wid; c < nc; c += BA_NW) {
+            const v4d d = cam_block_mfma(J, res, A.cobs_list, A.cobs_start[c], A.cobs_start[c + 1], lane);
+            const int col = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = (lane >> 4) + 4 * r;
+                if (row < 6) {
+                    if (col < 6) S[(size_t)(6 * c + row) * m + 6 * c + col] = d[r];
+                    else if (col == 6) rhs[6 * c + row] = d[r];
+                }
+            }
+        }
+    };
 
     for (;;) {
         // ================= (re-)evaluate cost, corrected residuals and Jacobians at x ======================================
@@ -296,20 +353,11 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
             if (tid == 0) { st.x_cost = xc; st.x_norm = sqrt(xn); if (st.first) A.summary[0] = xc; }
             __syncthreads();
             if (st.first) {
-                // jacobian column norms -> scale = 1/(1+||col||); cameras by tree reduction, points by their obs lists
-                for (int c = 0; c < nc; c++) {
-                    double acc[6] = {0, 0, 0, 0, 0, 0};
-                    for (int e = A.cobs_start[c] + tid; e < A.cobs_start[c + 1]; e += BA_T) {
-                        const double* Jc = J + (size_t)A.cobs_list[e] * 18;
-#pragma unroll
-                        for (int k = 0; k < 6; k++) acc[k] += Jc[k] * Jc[k] + Jc[6 + k] * Jc[6 + k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        const double s = block_sum(acc[k], red);
-                        if (tid == 0) scale[6 * c + k] = 1.0 / (1.0 + sqrt(s));
-                    }
-                }
+                // jacobian column norms -> scale = 1/(1+||col||): cameras from the diagonal of the (unscaled) camera blocks,
+                // points from their observation lists
+                camera_blocks();
+                __syncthreads();
+                for (int i = tid; i < m; i += BA_T) scale[i] = 1.0 / (1.0 + sqrt(S[(size_t)i * m + i]));
                 for (int p = tid; p < np; p += BA_T) {
                     double acc[3] = {0, 0, 0};
                     for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
@@ -344,59 +392,10 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         __syncthreads();
         if (st.done) break;
 
-        // ================= camera blocks: U_c = sum Jc^T Jc, rhs_c = sum Jc^T r (tree reductions) ===========================
+        // ================= camera blocks: U_c = sum Jc^T Jc, rhs_c = sum Jc^T r (one MFMA wavefront per camera) ==============
         for (int i = tid; i < m * m; i += BA_T) S[i] = 0.0;
         __syncthreads();
-        // per camera, in chunks of CB_CH observations: every observation's 27 products (21 of Jc^T Jc, 6 of Jc^T r) go to an
-        // LDS tile [27][CB_CH]; 27 x 8 threads add 1/8 of a column each, then 27 threads add the 8 partials in order.
-        for (int c = 0; c < nc; c++) {
-            const int e0 = A.cobs_start[c], e1 = A.cobs_start[c + 1];
-            double tot = 0;   // running total of value `tid` (tid < 27) across the chunks of this camera
-            for (int cb = e0; cb < e1; cb += CB_CH) {
-                const int cnt = min(CB_CH, e1 - cb);
-                if (tid < cnt) {
-                    const int i = A.cobs_list[cb + tid];
-                    const double* Jc = J + (size_t)i * 18;
-                    double jc[12];
-#pragma unroll
-                    for (int k = 0; k < 12; k++) jc[k] = Jc[k];
-                    const double r0 = res[2 * i], r1 = res[2 * i + 1];
-                    int k = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) {
-#pragma unroll
-                        for (int b = a; b < 6; b++) { ctile[k * CB_CH + tid] = jc[a] * jc[b] + jc[6 + a] * jc[6 + b]; k++; }
-                    }
-#pragma unroll
-                    for (int a = 0; a < 6; a++) ctile[(21 + a) * CB_CH + tid] = jc[a] * r0 + jc[6 + a] * r1;
-                }
-                __syncthreads();
-                if (tid < 27 * 8) {
-                    const int k = tid >> 3, part = tid & 7;
-                    const int lo = part * (CB_CH / 8), hi = min(cnt, lo + CB_CH / 8);
-                    double sacc = 0;
-                    for (int j = lo; j < hi; j++) sacc += ctile[k * CB_CH + j];
-                    cred[k * 8 + part] = sacc;
-                }
-                __syncthreads();
-                if (tid < 27) {
-                    double sacc = cred[tid * 8];
-#pragma unroll
-                    for (int q = 1; q < 8; q++) sacc += cred[tid * 8 + q];
-                    tot += sacc;
-                }
-                __syncthreads();
-            }
-            if (tid < 27) {
-                if (tid < 21) {
-                    int a = 0, k = tid;
-                    while (k >= 6 - a) { k -= 6 - a; a++; }
-                    const int b = a + k;
-                    S[(size_t)(6 * c + a) * m + 6 * c + b] = tot;
-                    S[(size_t)(6 * c + b) * m + 6 * c + a] = tot;
-                } else rhs[6 * c + (tid - 21)] = tot;
-            }
-        }
+        camera_blocks();
         __syncthreads();
         STAMP(1);
         // ================= LM diagonal ======================================================================================
@@ -421,15 +420,16 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         __syncthreads();
         for (int i = tid; i < m; i += BA_T) S[(size_t)i * m + i] += D2[i];
         STAMP(2);
-        // ================= point blocks: E^-1, g, dense rows of Yd and [Wd | g] =============================================
-        for (int i = tid; i < krows * ldw; i += BA_T) { Yd[i] = 0.0; Wd[i] = 0.0; }
+        // ================= point blocks: E^-1, g, and the point's three K-columns of Yt and [Wt | g] =========================
         if (tid == 0) st.chol_fail = 0;
         __syncthreads();
         double gmax_p = 0;
         for (int p = tid; p < np; p += BA_T) {
             double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+            unsigned seen = 0;
             for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
                 const int i = A.pobs_list[e];
+                seen |= 1u << A.cam_idx[i];
                 const double* Jp = J + (size_t)i * 18 + 12;
                 const double r0 = res[2 * i], r1 = res[2 * i + 1];
 #pragma unroll
@@ -473,7 +473,19 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
 #pragma unroll
             for (int k = 0; k < 9; k++) Einv[(size_t)p * 9 + k] = Ei[k];
 #pragma unroll
-            for (int k = 0; k < 3; k++) { gp[(size_t)p * 3 + k] = gv[k]; Wd[(size_t)(3 * p + k) * ldw + m] = gv[k]; }
+            for (int k = 0; k < 3; k++) { gp[(size_t)p * 3 + k] = gv[k]; Wt[(size_t)m * krows + 3 * p + k] = gv[k]; }
+            // cameras that do not see this point: zero K-columns (adjacent points -> adjacent addresses, coalesced)
+            for (int c = 0; c < nc; c++) {
+                if (seen & (1u << c)) continue;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        Wt[(size_t)(6 * c + a) * krows + 3 * p + b] = 0.0;
+                        Yt[(size_t)(6 * c + a) * krows + 3 * p + b] = 0.0;
+                    }
+                }
+            }
             for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
                 const int i = A.pobs_list[e];
                 const int c = A.cam_idx[i];
@@ -489,10 +501,10 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
 #pragma unroll
                     for (int b = 0; b < 3; b++) {
                         const double y = w3[0] * Ei[0 * 3 + b] + w3[1] * Ei[1 * 3 + b] + w3[2] * Ei[2 * 3 + b];
-                        double* wp = &Wd[(size_t)(3 * p + b) * ldw + 6 * c + a];
-                        double* yp = &Yd[(size_t)(3 * p + b) * ldw + 6 * c + a];
+                        double* wp = &Wt[(size_t)(6 * c + a) * krows + 3 * p + b];
+                        double* yp = &Yt[(size_t)(6 * c + a) * krows + 3 * p + b];
                         if (dup) { *wp += w3[b]; *yp += y; }      // two features of one frame on the same landmark (rare)
-                        else { *wp = w3[b]; *yp = y; }             // rows were zeroed: plain stores, no load in the way
+                        else { *wp = w3[b]; *yp = y; }
                     }
                 }
             }
@@ -508,7 +520,10 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         bool valid = !st.chol_fail;
         if (valid) {
             STAMP(4);
-            // ================= Schur complement on FP64 MFMA: G = Yd^T [Wd | g]  (m_pad x ncol_pad, K = krows) =============
+            // ================= Schur complement on FP64 MFMA: G = Y^T [W | g]  (m_pad x ncol_pad, K = krows) ================
+            // Operands are K-contiguous ([column][k]); a lane fetches 4 consecutive k (32 B) per operand and 16 k are consumed
+            // by 4 MFMAs: in MFMA s, lane group g supplies k = k0 + 4g + s for both operands (any pairing of k is a valid
+            // order of the sum).
             const int tr = A.tiles_r, tc = A.tiles_c, ks = A.kslices, kper = A.kper;
             const int items = tr * tc * ks;
             for (int it = wid; it < items; it += BA_NW) {
@@ -516,13 +531,28 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
                 const int ti = tile / tc, tj = tile - ti * tc;
                 const int k0 = s * kper, k1 = min(krows, k0 + kper);
                 v4d acc = {0, 0, 0, 0};
-                const double* ya = Yd + (size_t)(lane >> 4) * ldw + ti * 16 + (lane & 15);
-                const double* wb = Wd + (size_t)(lane >> 4) * ldw + tj * 16 + (lane & 15);
-#pragma unroll 16
-                for (int k = k0; k < k1; k += 4) {
-                    const double a = ya[(size_t)k * ldw];
-                    const double b = wb[(size_t)k * ldw];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                const double* ya = Yt + (size_t)(ti * 16 + (lane & 15)) * krows + 4 * (lane >> 4);
+                const double* wb = Wt + (size_t)(tj * 16 + (lane & 15)) * krows + 4 * (lane >> 4);
+                const int nk = __builtin_amdgcn_readfirstlane((k1 - k0) / 16);
+                const double* pa = ya + k0;
+                const double* pb = wb + k0;
+                int kb = 0;
+                for (; kb + 4 <= nk; kb += 4) {   // 4 K-blocks (64 k): 8 x 32-byte loads per lane in flight, then 16 MFMAs
+                    v4d a4[4], b4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { a4[u] = *(const v4d*)(pa + 16 * u); b4[u] = *(const v4d*)(pb + 16 * u); }
+                    pa += 64; pb += 64;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[u][q], b4[u][q], acc, 0, 0, 0);
+                    }
+                }
+                for (; kb < nk; kb++) {
+                    const v4d a4 = *(const v4d*)pa, b4 = *(const v4d*)pb;
+                    pa += 16; pb += 16;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], acc, 0, 0, 0);
                 }
                 // D[row = (lane>>4) + 4*reg][col = lane&15]
 #pragma unroll
@@ -539,56 +569,43 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
             }
             __syncthreads();
             STAMP(5);
-            // ================= Cholesky of S + triangular solves: wave 0 only, wave-synchronous on LDS =====================
-            // lane l owns rows l, l+64, ... ; element (i,k) receives its updates in ascending j, the same order as a
-            // left-looking factorisation; forward substitution subtracts in ascending column order, backward in descending.
-            if (wid == 0) {
-                bool fail = false;
-                for (int j = 0; j < m && !fail; j++) {
+            // ================= Cholesky of S with the rhs carried as row m (forward substitution for free) ==================
+            // right-looking; element (i,k) receives its updates in ascending j — the order of a left-looking factorisation
+            // and of a row-oriented forward substitution. All 8 wavefronts share the trailing update.
+            for (int j = 0; j < m; j++) {
+                if (tid == 0) {
                     const double d = S[(size_t)j * m + j];
-                    if (!(d > 0.0)) { fail = true; break; }
-                    const double dj = sqrt(d);
-                    WAVE_SYNC();
-                    for (int i = lane; i < m; i += 64) {
-                        if (i == j) S[(size_t)j * m + j] = dj;
-                        else if (i > j) S[(size_t)i * m + j] /= dj;
-                    }
-                    WAVE_SYNC();
-                    {   // trailing update of the lower triangle, one element per lane-step
-                        const int rem = m - j - 1;
-                        for (int e = lane; e < rem * rem; e += 64) {
-                            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-                            if (k <= i) S[(size_t)i * m + k] -= S[(size_t)i * m + j] * S[(size_t)k * m + j];
-                        }
-                    }
-                    WAVE_SYNC();
+                    if (!(d > 0.0)) st.chol_fail = 1;
+                    else { sdj = sqrt(d); S[(size_t)j * m + j] = sdj; }
                 }
-                if (fail) { if (lane == 0) st.chol_fail = 1; }
-                else {
-                    for (int i = lane; i < m; i += 64) stepc[i] = rhs[i];
+                __syncthreads();
+                if (st.chol_fail) break;
+                const double dj = sdj;
+                for (int i = j + 1 + tid; i <= m; i += BA_T) S[(size_t)i * m + j] /= dj;   // row m = rhs row
+                __syncthreads();
+                const int rem = m - j - 1;   // columns j+1 .. m-1; rows j+1 .. m
+                for (int e = tid; e < (rem + 1) * rem; e += BA_T) {
+                    const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+                    if (k <= i) S[(size_t)i * m + k] -= S[(size_t)i * m + j] * S[(size_t)k * m + j];
+                }
+                __syncthreads();
+            }
+            valid = !st.chol_fail;
+            if (valid && wid == 0) {
+                // backward substitution on y = row m (column-oriented, descending), wave-synchronous
+                for (int i = lane; i < m; i += 64) stepc[i] = rhs[i];
+                WAVE_SYNC();
+                for (int i = m - 1; i >= 0; i--) {
+                    const double xi = stepc[i] / S[(size_t)i * m + i];
                     WAVE_SYNC();
-                    for (int j = 0; j < m; j++) {
-                        const double yj = stepc[j] / S[(size_t)j * m + j];
-                        WAVE_SYNC();
-                        for (int i = lane; i < m; i += 64) {
-                            if (i == j) stepc[j] = yj;
-                            else if (i > j) stepc[i] -= S[(size_t)i * m + j] * yj;
-                        }
-                        WAVE_SYNC();
+                    for (int k = lane; k < m; k += 64) {
+                        if (k == i) stepc[i] = xi;
+                        else if (k < i) stepc[k] -= S[(size_t)i * m + k] * xi;
                     }
-                    for (int i = m - 1; i >= 0; i--) {
-                        const double xi = stepc[i] / S[(size_t)i * m + i];
-                        WAVE_SYNC();
-                        for (int k = lane; k < m; k += 64) {
-                            if (k == i) stepc[i] = xi;
-                            else if (k < i) stepc[k] -= S[(size_t)i * m + k] * xi;
-                        }
-                        WAVE_SYNC();
-                    }
+                    WAVE_SYNC();
                 }
             }
             __syncthreads();
-            valid = !st.chol_fail;
         }
         if (valid) {
             STAMP(6);
@@ -695,8 +712,14 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
         if (st.need_eval == 2) {
             for (int i = tid; i < n; i += BA_T) x[i] = cand[i];
             __syncthreads();
-            if (tid == 0) st.need_eval = 1;
+            if (tid == 0) {
+                if (st.iter >= A.max_iterations) {
+                    // last permitted iteration accepted: the re-evaluation at the new x would only reproduce cand_cost
+                    st.x_cost = st.cand_cost; st.need_eval = 0; st.done = 1; st.termination = 0;
+                } else st.need_eval = 1;
+            }
             __syncthreads();
+            if (st.done) break;
         }
     }
     __syncthreads();
@@ -717,7 +740,7 @@ hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* 
 }
 hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A) {
     const int m = 6 * A.nc;
-    const size_t shm = ((size_t)m * m + 2 * (size_t)m + 27 * CB_CH) * sizeof(double);   // reduced camera system + camera-block tile
+    const size_t shm = ((size_t)(m + 1) * m + (size_t)m) * sizeof(double);   // [S | rhs row] + camera step, LDS-resident
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

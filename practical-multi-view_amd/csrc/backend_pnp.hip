@@ -638,30 +638,38 @@ __device__ inline void d_angle_axis_rotate_jac(const double a[3], const double q
 
 constexpr int RF_T = 256;
 struct RefitShared {
+    double tile[28 * 256];   // per-thread partials, [value][thread]
+    double part[28 * 8];
     double red[4 * 28];
+    double Aug[6 * 7];       // augmented normal equations of one LM step
     double JtJ[36], JtErr[6], param[6], prev[6];
     double err2, prevErr2;
     int best, last, n_in, state, lambdaLg10, iters, done;
     int wsum[4];
 };
 
-// sums 28 values over the block (fixed tree), result valid in thread 0..27 of sh.red[0..27]
-__device__ inline void block_sum28(double* acc, RefitShared& sh) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+// sums 28 per-thread values over the block in a fixed order: LDS tile [28][256], 28 x 8 threads add 32 consecutive
+// entries each, 28 threads add the 8 partials. Result in sh.red[0..27].
+__device__ inline void block_sum28(const double* acc, RefitShared& sh) {
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < 28; k++) {
-        double v = acc[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        acc[k] = v;
+    for (int k = 0; k < 28; k++) sh.tile[k * RF_T + tid] = acc[k];
+    __syncthreads();
+    if (tid < 28 * 8) {
+        const int k = tid >> 3, part = tid & 7;
+        const double* src = &sh.tile[k * RF_T + part * 32];
+        double sacc = 0;
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) sacc += src[j];
+        sh.part[k * 8 + part] = sacc;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid < 28) {
+        double sacc = sh.part[tid * 8];
 #pragma unroll
-        for (int k = 0; k < 28; k++) sh.red[wid * 28 + k] = acc[k];
+        for (int q = 1; q < 8; q++) sacc += sh.part[tid * 8 + q];
+        sh.red[tid] = sacc;
     }
-    __syncthreads();
-    if (tid < 28) sh.red[tid] = sh.red[tid] + sh.red[28 + tid] + sh.red[56 + tid] + sh.red[84 + tid];
     __syncthreads();
 }
 
@@ -783,35 +791,49 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
                     else { sh.prevErr2 = err2; sh.state = 0; }
                 }
             }
+            sh.state = do_step ? (sh.state | 2) : sh.state;   // bit 1: a step has to be solved by wave 0 below
             if (do_step) {
                 const double lambda = exp(sh.lambdaLg10 * log(10.));
-                double Am[36], b[6];
-                for (int i = 0; i < 36; i++) Am[i] = sh.JtJ[i];
-                for (int i = 0; i < 6; i++) { b[i] = sh.JtErr[i]; Am[i * 6 + i] *= 1. + lambda; }
-                bool ok = true;
-                for (int c = 0; c < 6 && ok; c++) {   // Gaussian elimination with partial pivoting
-                    int piv = c;
-                    for (int r = c + 1; r < 6; r++) if (fabs(Am[r * 6 + c]) > fabs(Am[piv * 6 + c])) piv = r;
-                    if (Am[piv * 6 + c] == 0.0) { ok = false; break; }
-                    if (piv != c) {
-                        for (int k = 0; k < 6; k++) { const double t = Am[c * 6 + k]; Am[c * 6 + k] = Am[piv * 6 + k]; Am[piv * 6 + k] = t; }
-                        const double t = b[c]; b[c] = b[piv]; b[piv] = t;
-                    }
-                    for (int r = c + 1; r < 6; r++) {
-                        const double f = Am[r * 6 + c] / Am[c * 6 + c];
-                        if (f == 0.0) continue;
-                        for (int k = c; k < 6; k++) Am[r * 6 + k] -= f * Am[c * 6 + k];
-                        b[r] -= f * b[c];
+                for (int i = 0; i < 6; i++) {
+                    for (int k = 0; k < 6; k++) sh.Aug[i * 7 + k] = sh.JtJ[i * 6 + k];
+                    sh.Aug[i * 7 + i] *= 1. + lambda;
+                    sh.Aug[i * 7 + 6] = sh.JtErr[i];
+                }
+            }
+        }
+        __syncthreads();
+        if ((sh.state & 2) && tid < 64) {
+            // Gaussian elimination with partial pivoting on [A | b]: lane r owns row r (same per-element expressions as the
+            // row-by-row loop), back substitution on lane 0
+            const int r = tid;
+            bool ok = true;
+            for (int c = 0; c < 6; c++) {
+                int piv = c;
+                double best = fabs(sh.Aug[c * 7 + c]);
+                for (int q = c + 1; q < 6; q++) { const double v = fabs(sh.Aug[q * 7 + c]); if (v > best) { best = v; piv = q; } }
+                if (sh.Aug[piv * 7 + c] == 0.0) { ok = false; break; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (piv != c && r < 7) { const double t = sh.Aug[c * 7 + r]; sh.Aug[c * 7 + r] = sh.Aug[piv * 7 + r]; sh.Aug[piv * 7 + r] = t; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (r > c && r < 6) {
+                    const double f = sh.Aug[r * 7 + c] / sh.Aug[c * 7 + c];
+                    if (f != 0.0) {
+                        for (int k = c; k < 7; k++) sh.Aug[r * 7 + k] -= f * sh.Aug[c * 7 + k];
                     }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (r == 0) {
+                double bb[6];
                 if (ok) {
-                    for (int r = 5; r >= 0; r--) {
-                        double v = b[r];
-                        for (int k = r + 1; k < 6; k++) v -= Am[r * 6 + k] * b[k];
-                        b[r] = v / Am[r * 6 + r];
+                    for (int q = 5; q >= 0; q--) {
+                        double v = sh.Aug[q * 7 + 6];
+                        for (int k = q + 1; k < 6; k++) v -= sh.Aug[q * 7 + k] * bb[k];
+                        bb[q] = v / sh.Aug[q * 7 + q];
                     }
-                } else for (int i = 0; i < 6; i++) b[i] = 0;
-                for (int i = 0; i < 6; i++) sh.param[i] = sh.prev[i] - b[i];
+                } else for (int i = 0; i < 6; i++) bb[i] = 0;
+                for (int i = 0; i < 6; i++) sh.param[i] = sh.prev[i] - bb[i];
+                sh.state &= 1;
             }
         }
         __syncthreads();

@@ -11,6 +11,7 @@
 #include "vo_pipeline.h"
 #include "vo_math.h"
 #include <cfloat>
+#include <thread>
 
 namespace vo {
 namespace {
@@ -357,7 +358,8 @@ int recover_pose(const double* E, const double* p1, const double* p2, int n, con
     std::vector<std::vector<uint8_t>> masks(4, std::vector<uint8_t>(n, 0));
     std::vector<std::vector<double>> tris(4, std::vector<double>((size_t)4 * n));
     int good[4] = {0, 0, 0, 0};
-    for (int c = 0; c < 4; c++) {
+    // the four (R, t) hypotheses are independent: one host thread each (cv::recoverPose evaluates them one after another)
+    auto eval_combo = [&](int c) {
         double P1[12];
         for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) P1[i * 4 + j] = Rs[c][i * 3 + j]; P1[i * 4 + 3] = tsgn[c] * tv[i]; }
         const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -390,6 +392,14 @@ int recover_pose(const double* E, const double* p1, const double* p2, int n, con
             masks[c][i] = m ? 1 : 0;
             good[c] += m ? 1 : 0;
         }
+    };
+    if (n >= 64) {
+        std::thread th[3];
+        for (int c = 1; c < 4; c++) th[c - 1] = std::thread(eval_combo, c);
+        eval_combo(0);
+        for (auto& t : th) t.join();
+    } else {
+        for (int c = 0; c < 4; c++) eval_combo(c);
     }
     int sel;
     if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) sel = 0;
