@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=150, help="bounded sample for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--sequential", action="store_true", help="one host thread instead of front-end/back-end threads")
+    ap.add_argument("--batch", type=int, default=8, help="extra leg: B independent sequences concurrently on the GPU (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +159,42 @@ def main():
                    sample=f"first {m} frames of the same sequence; oracle pipeline, front-end + back-end threads, LK over {nthr} worker threads",
                    seconds=round(dt, 3))
 
+    # ---- batched leg: B independent sequences on ONE GPU, one context + front/back host threads each ----------
+    batched = None
+    if args.batch > 1 and world == 1:
+        import threading
+        B = args.batch
+        ctxs = [ctx] + [pmv.Context(w, h, n_slots=n, max_tracks=4096, max_ba_cams=32, max_ba_points=8192, max_ba_obs=65536, device=local_rank)
+                        for _ in range(B - 1)]
+        for c in ctxs[1:]:
+            c.frames_stage(0, frames)      # the same frames in every context: a throughput leg, every run is a full independent pass
+        results = [None] * B
+
+        def worker(i):
+            results[i] = ctxs[i].pipeline_run(n, w, h, K, gt, min_tracked=wl["min_tracked"], tol=wl["tol"], init_frames=wl["init_frames"],
+                                              bundle_size=wl["bundle_size"], ba_iterations=wl["ba_iterations"], threaded=1, build_pyramids=1,
+                                              want_features=False)
+
+        def run_all():
+            th = [threading.Thread(target=worker, args=(i,)) for i in range(B)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        run_all()                          # warm-up
+        for c in ctxs:
+            c.sync()
+        t0 = time.perf_counter()
+        run_all()
+        for c in ctxs:
+            c.sync()
+        dtb = time.perf_counter() - t0
+        same = all(np.array_equal(results[i].poses, res.poses) for i in range(B))
+        batched = dict(sequences=B, value=round(B * frames_per_step / dtb, 3), unit="frames/s", seconds=round(dtb, 3),
+                       host_threads=2 * B, identical_to_single_run=bool(same))
+        for c in ctxs[1:]:
+            c.close()
+
     # trajectory sanity vs synthetic ground truth (z flipped: the pipeline's forward axis is -z, quirk Q14)
     off = int(st["init_offset"])
     est = res.poses[:, 9:12]
@@ -175,6 +212,7 @@ def main():
                    "frames_per_step": frames_per_step, "host_threads": 1 if args.sequential else 2},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "batched": batched,
         "kernels": kern,
         "pipeline_stats": {k: st[k] for k in ("lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls",
                                               "ba_obs", "ba_points", "heuristic_motion", "n_landmarks")},

@@ -9,6 +9,7 @@ struct BAArgs {
     // problem (device)
     double* cams; double* pts; const double* obs; const int* cam_idx; const int* pt_idx; const double* K;
     const int* pobs_start; const int* pobs_list; const int* cobs_start; const int* cobs_list;
+    const int* odup;   // per entry of pobs_list: 0 = only observation of its (point, camera), 1 = first of several, 2 = a later one
     int nc, np, nobs, max_iterations;
     double huber;
     // workspaces (device)
@@ -20,6 +21,8 @@ struct BAArgs {
 hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,
                                const int* pt_idx, int nobs, const double* K, double* out_r, double* out_J);
 hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A);
+// multi-kernel LM (default); d_state: >= 512 B, d_part: >= (nobs/256 + 5*np/64 + 58*nc + 3*nobs + 8) doubles
+hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double* d_part);
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
                       double* d_rt_out, int* d_inliers, int* d_info);

@@ -21,6 +21,8 @@ struct BackendBuffers {
            *d_Gpart = nullptr, *d_summary = nullptr;
     size_t ydwd_elems = 0, gpart_elems = 0;
     unsigned long long* d_stamps = nullptr;
+    void* d_bastate = nullptr;
+    double* d_bapart = nullptr;
     // single-copy transfers: one pinned staging block and one device block per direction
     void* h_stage = nullptr;
     size_t h_stage_bytes = 0;
@@ -49,17 +51,19 @@ int backend_create(pmv_ctx* c) {
     CKB(hipMalloc(&b->d_cam_idx, no * 4)); CKB(hipMalloc(&b->d_pt_idx, no * 4));
     CKB(hipMalloc(&b->d_pobs_start, (np + 1) * 4)); CKB(hipMalloc(&b->d_pobs_list, no * 4));
     CKB(hipMalloc(&b->d_cobs_start, (nc + 1) * 4)); CKB(hipMalloc(&b->d_cobs_list, no * 4));
-    CKB(hipMalloc(&b->d_x, n * 8)); CKB(hipMalloc(&b->d_cand, n * 8)); CKB(hipMalloc(&b->d_scale, n * 8)); CKB(hipMalloc(&b->d_diag, n * 8));
+    CKB(hipMalloc(&b->d_x, 2 * n * 8)); CKB(hipMalloc(&b->d_cand, n * 8)); CKB(hipMalloc(&b->d_scale, n * 8)); CKB(hipMalloc(&b->d_diag, n * 8));
     CKB(hipMalloc(&b->d_D2, n * 8)); CKB(hipMalloc(&b->d_step, n * 8));
     CKB(hipMalloc(&b->d_res, no * 2 * 8)); CKB(hipMalloc(&b->d_J, no * 18 * 8));
     CKB(hipMalloc(&b->d_Einv, np * 9 * 8)); CKB(hipMalloc(&b->d_gp, np * 3 * 8));
     b->ydwd_elems = krows * ldw;
-    CKB(hipMalloc(&b->d_Yd, b->ydwd_elems * 8)); CKB(hipMalloc(&b->d_Wd, b->ydwd_elems * 8));
+    CKB(hipMalloc(&b->d_Yd, 2 * b->ydwd_elems * 8)); CKB(hipMalloc(&b->d_Wd, b->ydwd_elems * 8));
     CKB(hipMalloc(&b->d_S, m * m * 8)); CKB(hipMalloc(&b->d_rhs, m * 8));
     b->gpart_elems = (size_t)8 * ldw * ldw;   // up to 8 K-slices of an (ldw x ldw) tile grid
     CKB(hipMalloc(&b->d_Gpart, b->gpart_elems * 8));
     CKB(hipMalloc(&b->d_summary, 8 * 8));
     CKB(hipMalloc(&b->d_stamps, 32 * 8));
+    CKB(hipMalloc(&b->d_bastate, 512));
+    CKB(hipMalloc(&b->d_bapart, ((size_t)(no + 255) / 256 + 5 * ((size_t)(np + 63) / 64) + 64 * (size_t)nc + 3 * (size_t)no + 64) * 8));
     CKB(hipMemset(b->d_stamps, 0, 32 * 8));
     const size_t mt = (size_t)c->max_tracks;
     b->h_stage_bytes = std::max<size_t>(no * 18 * 8 + no * 2 * 8, std::max<size_t>(n * 8 + no * 32 + (np + nc + 2) * 4, mt * 32 + MAX_HYP * 20 + 4096));
@@ -69,7 +73,7 @@ int backend_create(pmv_ctx* c) {
     CKB(hipMalloc(&b->d_inliers, mt * 4)); CKB(hipMalloc(&b->d_info, 16));
     CKB(hipMalloc(&b->d_models, MAX_HYP * 6 * 8)); CKB(hipMalloc(&b->d_rt, 6 * 8)); CKB(hipMalloc(&b->d_Kp, 9 * 8));
     CKB(hipMalloc(&b->d_masks, (size_t)MAX_HYP * mt));
-    b->ba_io_bytes = (8 + nc * 6 + np * 3 + no * 2 + 10) * 8 + (no * 4 + np + nc + 8) * 4 + 64;
+    b->ba_io_bytes = (8 + nc * 6 + np * 3 + no * 2 + 10) * 8 + (no * 5 + np + nc + 8) * 4 + 64;
     CKB(hipMalloc(&b->d_ba_io, b->ba_io_bytes));
     b->pnp_in_bytes = 80 + mt * 20 + (size_t)MAX_HYP * 20 + 64;
     b->pnp_out_bytes = 48 + 16 + mt * 4 + 64;
@@ -88,7 +92,7 @@ void backend_destroy(pmv_ctx* c) {
     void* ptrs[] = {b->d_cams, b->d_pts, b->d_obs, b->d_K, b->d_cam_idx, b->d_pt_idx, b->d_pobs_start, b->d_pobs_list, b->d_cobs_start,
                     b->d_cobs_list, b->d_x, b->d_cand, b->d_scale, b->d_diag, b->d_D2, b->d_step, b->d_res, b->d_J, b->d_Einv, b->d_gp,
                     b->d_Yd, b->d_Wd, b->d_S, b->d_rhs, b->d_Gpart, b->d_summary, b->d_obj, b->d_img, b->d_samples, b->d_counts,
-                    b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out};
+                    b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out, b->d_bastate, b->d_bapart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     delete b;
@@ -243,7 +247,8 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     int* h_ci = (int*)(h_K + 10);
     int* h_pi = h_ci + n_obs;
     int* pstart = h_pi + n_obs; int* plist = pstart + (np + 1); int* cstart = plist + n_obs; int* clist = cstart + (nc + 1);
-    const size_t io_bytes = (size_t)((char*)(clist + n_obs) - hs);
+    int* odup = clist + n_obs;
+    const size_t io_bytes = (size_t)((char*)(odup + n_obs) - hs);
     memcpy(h_cams, cams, (size_t)nc * 48); memcpy(h_pts, pts, (size_t)np * 24); memcpy(h_obs, obs_xy, (size_t)n_obs * 16);
     memcpy(h_K, K, 72); memcpy(h_ci, cam_idx, (size_t)n_obs * 4); memcpy(h_pi, pt_idx, (size_t)n_obs * 4);
     // observation lists per point / per camera (counting sort, observation order preserved)
@@ -259,6 +264,16 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
         std::vector<int> pf(pstart, pstart + np), cf(cstart, cstart + nc);
         for (int i = 0; i < n_obs; i++) { plist[pf[pt_idx[i]]++] = i; clist[cf[cam_idx[i]]++] = i; }
     }
+    // a point seen twice by the same camera (the reference's feat_corr duplicates): the first entry carries the group
+    for (int p = 0; p < np; p++) {
+        for (int e = pstart[p]; e < pstart[p + 1]; e++) {
+            const int c = cam_idx[plist[e]];
+            bool earlier = false, later = false;
+            for (int e2 = pstart[p]; e2 < e; e2++) earlier = earlier || cam_idx[plist[e2]] == c;
+            for (int e2 = e + 1; e2 < pstart[p + 1]; e2++) later = later || cam_idx[plist[e2]] == c;
+            odup[e] = earlier ? 2 : (later ? 1 : 0);
+        }
+    }
     REQ(io_bytes <= b->ba_io_bytes, PMV_ERR_CAPACITY, "pmv_ba_solve: io block too small");
     CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
     char* dio = b->d_ba_io;
@@ -270,9 +285,10 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     int* d_ci = (int*)(d_K + 10);
     int* d_pi = d_ci + n_obs;
     int* d_pstart = d_pi + n_obs; int* d_plist = d_pstart + (np + 1); int* d_cstart = d_plist + n_obs; int* d_clist = d_cstart + (nc + 1);
+    int* d_odup = d_clist + n_obs;
     BAArgs A;
     A.cams = d_cams; A.pts = d_pts; A.obs = d_obs; A.cam_idx = d_ci; A.pt_idx = d_pi; A.K = d_K;
-    A.pobs_start = d_pstart; A.pobs_list = d_plist; A.cobs_start = d_cstart; A.cobs_list = d_clist;
+    A.pobs_start = d_pstart; A.pobs_list = d_plist; A.cobs_start = d_cstart; A.cobs_list = d_clist; A.odup = d_odup;
     A.nc = nc; A.np = np; A.nobs = n_obs; A.max_iterations = max_iterations; A.huber = huber_delta;
     A.x = b->d_x; A.cand = b->d_cand; A.scale = b->d_scale; A.diag = b->d_diag; A.D2 = b->d_D2; A.step = b->d_step; A.res = b->d_res; A.J = b->d_J;
     A.Einv = b->d_Einv; A.gp = b->d_gp; A.Yd = b->d_Yd; A.Wd = b->d_Wd; A.S = b->d_S; A.rhs = b->d_rhs; A.Gpart = b->d_Gpart; A.summary = d_sum;
@@ -285,15 +301,59 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     int ks = 8 / (A.tiles_r * A.tiles_c);
     if (ks < 1) ks = 1;
     if (ks > 8) ks = 8;
+    if (!getenv("PMV_BA_SINGLE")) ks = 8;   // multi-kernel path: one wavefront per (tile, K-slice) anywhere on the chip
     A.kper = round_up((A.krows + ks - 1) / ks, 16);
     A.kslices = (A.krows + A.kper - 1) / A.kper;
     REQ((size_t)A.krows * A.ldw <= b->ydwd_elems && (size_t)A.kslices * A.gp_rows * A.ldw <= b->gpart_elems, PMV_ERR_CAPACITY, "pmv_ba_solve: workspace too small");
     REQ(((size_t)(m + 1) * m + (size_t)m) * 8 <= 150 * 1024, PMV_ERR_CAPACITY, "pmv_ba_solve: %d cameras exceed the LDS-resident reduced system (max 22)", nc);
-    CKC(launch_ba_lm(s, A));
+    // x holds two parameter vectors (current / candidate) in the multi-kernel solver
+    static const bool single = getenv("PMV_BA_SINGLE") != nullptr;   // A/B switch: the one-workgroup persistent kernel
+    static const bool check = getenv("PMV_BA_CHECK") != nullptr;
+    std::vector<char> saved;
+    if (check) saved.assign(hs, hs + io_bytes);
+    if (single) CKC(launch_ba_lm(s, A));
+    else { A.Wd = A.Yd + (size_t)A.krows * A.ldw; CKC(launch_ba_multi(s, A, b->d_bastate, b->d_bapart)); }
     const size_t out_bytes = (8 + (size_t)nc * 6 + (size_t)np * 3) * 8;
     CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));
     CKC(hipStreamSynchronize(s));
     const double* h_out = (const double*)hs;
+    if (!single && check) {   // diagnostic: the same problem through the one-workgroup kernel, differences to stderr
+        std::vector<double> got(h_out, h_out + out_bytes / 8);
+        CKC(hipMemcpyAsync(b->d_ba_io, saved.data(), io_bytes, hipMemcpyHostToDevice, s));
+        A.Wd = b->d_Wd;
+        CKC(launch_ba_lm(s, A));
+        CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));
+        CKC(hipStreamSynchronize(s));
+        double dmax = 0;
+        for (size_t i = 8; i < out_bytes / 8; i++) dmax = std::max(dmax, fabs(got[i] - h_out[i]));
+        fprintf(stderr, "[ba-check] nc=%d np=%d nobs=%d multi: cost %.12g -> %.12g it %d ok %d term %d | single: %.12g -> %.12g it %d ok %d term %d | max|dx| %.3e\n",
+                nc, np, n_obs, got[0], got[1], (int)got[2], (int)got[3], (int)got[4], h_out[0], h_out[1], (int)h_out[2], (int)h_out[3],
+                (int)h_out[4], dmax);
+        {   // sensitivity: the same problem with the cameras perturbed by 1e-9 (how much does one solve amplify?)
+            std::vector<double> base(h_out, h_out + out_bytes / 8);
+            std::vector<char> pert(saved);
+            double* pc = (double*)pert.data() + 8;
+            for (int i = 0; i < 6 * nc; i++) pc[i] += 1e-9 * ((i * 2654435761u >> 7) % 3 - 1.0);
+            CKC(hipMemcpyAsync(b->d_ba_io, pert.data(), io_bytes, hipMemcpyHostToDevice, s));
+            CKC(launch_ba_lm(s, A));
+            CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));
+            CKC(hipStreamSynchronize(s));
+            double d2 = 0;
+            for (size_t i = 8; i < out_bytes / 8; i++) d2 = std::max(d2, fabs(base[i] - h_out[i]));
+            fprintf(stderr, "[ba-check]    input perturbed by 1e-9 -> single-kernel output moves by %.3e\n", d2);
+        }
+        memcpy(hs, got.data(), out_bytes);
+    }
+    if (getenv("PMV_BA_TRACE")) {   // diagnostic: first / last camera before and after the solve
+        fprintf(stderr, "[ba-trace] nc=%d np=%d nobs=%d cost %.15g -> %.15g it %d ok %d\n", nc, np, n_obs, h_out[0], h_out[1], (int)h_out[2], (int)h_out[3]);
+        for (int c : {0, nc - 1}) {
+            fprintf(stderr, "[ba-trace]   cam %d in ", c);
+            for (int k = 0; k < 6; k++) fprintf(stderr, " %.15g", cams[6 * c + k]);
+            fprintf(stderr, "\n[ba-trace]   cam %d out", c);
+            for (int k = 0; k < 6; k++) fprintf(stderr, " %.15g", h_out[8 + 6 * c + k]);
+            fprintf(stderr, "\n");
+        }
+    }
     memcpy(cams, h_out + 8, (size_t)nc * 48);
     memcpy(pts, h_out + 8 + (size_t)nc * 6, (size_t)np * 24);
     if (summary) {

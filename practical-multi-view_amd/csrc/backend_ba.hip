@@ -229,6 +229,12 @@ __device__ inline void huber_rho(double s, double a, double& rho0, double& rho1)
     } else { rho0 = s; rho1 = 1; }
 }
 
+// v[lane l] for a wave-uniform l (v_readlane_b32 x2)
+__device__ inline double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 #define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // Camera blocks on FP64 MFMA: for camera c, F = the 2*n_c rows of its observations with columns [Jc(6) | r | 0...]; one
@@ -729,6 +735,750 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
     if (tid == 0) {
         A.summary[1] = st.x_cost; A.summary[2] = st.iter; A.summary[3] = st.successful; A.summary[4] = st.termination;
     }
+}
+
+// =========================================================================================================================
+// Multi-kernel LM (the default path): the same iteration as k_ba_lm with every data-parallel phase spread over many CUs —
+// one CU moves only ~10 B/clk and an FP64 dependency chain costs ~18 clk/op, so a single workgroup is bound by its own
+// bandwidth and latency. All decisions stay on the device: the host enqueues a fixed chain of launches
+//     E (accept/reject of the previous step + r, J at the new point)  ->  C|P (camera blocks on MFMA | point blocks)  ->
+//     G (Schur contraction on MFMA, one wavefront per tile x K-slice)  ->  S (reduced system, Cholesky)  ->  B (back-
+//     substitution, candidate, model-cost and candidate-cost terms)
+// per LM iteration; every kernel reads the device-side state and returns at once when the solve has terminated. Kernel
+// boundaries are the only grid-wide synchronisation (no cooperative launch, no spinning), all sums have a fixed order.
+// The state is double-buffered so that E can evaluate the decision redundantly in every block while block 0 publishes it.
+// =========================================================================================================================
+struct BAGState {
+    double x_cost, cand_cost, x_norm, radius, decrease, gmax, model_change, step_norm, initial_cost;
+    int iter, reuse_diag, invalid, need_eval, done, termination, successful, chol_fail, first, cur, step_valid, max_iterations;
+};
+constexpr int BM_T = 256;          // threads per block of the E / C|P / S / B kernels
+constexpr int BM_NW = BM_T / 64;
+
+// accept / reject, trust-region update, termination (ceres TrustRegionMinimizer) on a private copy of the state
+__device__ inline void bam_decide(BAGState& s, const double* __restrict__ part4, int nbp) {
+    s.iter++;
+    s.first = 0;
+    bool valid = s.step_valid != 0;
+    double mc = 0, cc = 0, dn2 = 0;
+    if (valid) {
+        for (int b = 0; b < nbp; b++) { mc += part4[b * 4]; cc += part4[b * 4 + 1]; dn2 += part4[b * 4 + 2]; }
+        s.model_change = mc;
+        valid = mc > 0.0;
+    }
+    s.chol_fail = 0;
+    if (!valid) {   // HandleInvalidStep
+        if (++s.invalid >= 5) { s.done = 1; s.termination = 4; }
+        else { s.radius /= s.decrease; s.decrease *= 2; s.reuse_diag = 1; }
+        s.need_eval = 0;
+        return;
+    }
+    s.invalid = 0;
+    s.cand_cost = cc;
+    s.step_norm = sqrt(dn2);
+    const double cost_change = s.x_cost - cc;
+    if (s.step_norm <= 1e-8 * (s.x_norm + 1e-8)) { s.done = 1; s.termination = 3; return; }
+    if (fabs(cost_change) <= 1e-6 * s.x_cost) { s.done = 1; s.termination = 1; return; }
+    const double rel = cost_change / mc;
+    if (rel > 1e-3) {
+        s.cur ^= 1;
+        s.successful++;
+        const double t = 2.0 * rel - 1.0;
+        s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+        s.radius = fmin(1e16, s.radius);
+        s.decrease = 2.0;
+        s.reuse_diag = 0;
+        s.need_eval = 1;
+        if (s.iter >= s.max_iterations) { s.x_cost = cc; s.done = 1; s.termination = 0; }
+    } else {
+        s.radius /= s.decrease; s.decrease *= 2; s.reuse_diag = 1;
+        s.need_eval = 0;
+    }
+}
+
+// E: decision on the previous step (it > 0), then r and J (Huber-corrected, Jacobi-scaled once the scaling exists) at the
+// current point; one thread per observation; cost partial per block.
+__global__ __launch_bounds__(BM_T) void k_bam_eval(BAArgs A, const BAGState* __restrict__ st_in, BAGState* __restrict__ st_out,
+                                                   const double* __restrict__ part4, int nbp, int it,
+                                                   double* __restrict__ part_cost) {
+    __shared__ BAGState ss;
+    __shared__ double red[BM_NW];
+    const int tid = threadIdx.x;
+    const int n = 6 * A.nc + 3 * A.np;
+    if (tid == 0) {
+        if (it == 0) {
+            ss.radius = 1e4; ss.decrease = 2.0; ss.iter = 0; ss.reuse_diag = 0; ss.invalid = 0; ss.need_eval = 1; ss.done = 0;
+            ss.termination = 0; ss.successful = 0; ss.chol_fail = 0; ss.first = 1; ss.cur = 0; ss.step_valid = 0;
+            ss.gmax = -1.0; ss.x_cost = 0; ss.initial_cost = 0; ss.max_iterations = A.max_iterations; ss.x_norm = 0;
+            ss.cand_cost = 0; ss.model_change = 0; ss.step_norm = 0;
+        } else {
+            ss = *st_in;
+            if (!ss.done) bam_decide(ss, part4, nbp);
+        }
+        if (blockIdx.x == 0) *st_out = ss;
+    }
+    __syncthreads();
+    if (ss.done || !ss.need_eval) return;
+    const double* xc; const double* xp;
+    if (it == 0) {   // the parameter vector starts as the caller's cameras and points
+        xc = A.cams; xp = A.pts;
+        for (int i = blockIdx.x * BM_T + tid; i < n; i += gridDim.x * BM_T) A.x[i] = (i < 6 * A.nc) ? A.cams[i] : A.pts[i - 6 * A.nc];
+    } else { xc = A.x + (size_t)ss.cur * n; xp = xc + 6 * A.nc; }
+    const int i = blockIdx.x * BM_T + tid;
+    double cpart = 0;
+    if (i < A.nobs) {
+        const int c = A.cam_idx[i], p = A.pt_idx[i];
+        CamRot cr;
+        cam_rot_setup(xc + 6 * c, cr);
+        double r[2], Jc[12], Jp[6];
+        projection_residual_pre(cr, xc + 6 * c, xp + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, Jc, Jp, true);
+        double rho0, rho1;
+        huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
+        cpart = 0.5 * rho0;
+        const double sr = sqrt(rho1);
+        A.res[2 * i] = r[0] * sr; A.res[2 * i + 1] = r[1] * sr;
+        double* Jo = A.J + (size_t)i * 18;
+        if (ss.first) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) Jo[k] = Jc[k] * sr;
+#pragma unroll
+            for (int k = 0; k < 6; k++) Jo[12 + k] = Jp[k] * sr;
+        } else {
+            const double* sc = A.scale + 6 * c;
+            const double* sp = A.scale + 6 * A.nc + 3 * p;
+#pragma unroll
+            for (int k = 0; k < 12; k++) Jo[k] = Jc[k] * sr * sc[k % 6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Jo[12 + k] = Jp[k] * sr * sp[k % 3];
+        }
+    }
+    cpart = wave_sum_f64(cpart);
+    if ((tid & 63) == 0) red[tid >> 6] = cpart;
+    __syncthreads();
+    if (tid == 0) part_cost[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// C role: one block (4 wavefronts) per camera: U_c (6x6) and rhs_c on FP64 MFMA; in the first iteration also the Jacobi
+// scale of the camera's parameters (from the unscaled column norms = diag U_c) and the rescaled block.
+__device__ inline void bam_cam_role(const BAArgs& A, const BAGState* __restrict__ st, int c, double* __restrict__ Ublk,
+                                    double* __restrict__ rhsblk, double* sred /* [BM_NW][64][4] */, double* ssc /* 8 */) {
+    if (st->done || !st->need_eval) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int e0 = A.cobs_start[c], e1 = A.cobs_start[c + 1];
+    const int per = (((e1 - e0) + BM_NW - 1) / BM_NW + 7) & ~7;   // observations per wavefront, whole MFMA batches (8 obs)
+    const int w0 = min(e1, e0 + wid * per), w1 = min(e1, w0 + per);
+    const v4d d = cam_block_mfma(A.J, A.res, A.cobs_list, w0, w1, lane);
+#pragma unroll
+    for (int r = 0; r < 4; r++) sred[(wid * 4 + r) * 64 + lane] = d[r];
+    __syncthreads();
+    if (wid != 0) return;
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = (sred[(0 * 4 + r) * 64 + lane] + sred[(1 * 4 + r) * 64 + lane]) + (sred[(2 * 4 + r) * 64 + lane] + sred[(3 * 4 + r) * 64 + lane]);
+    const int col = lane & 15;
+    const bool first = st->first != 0;
+    if (first) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = (lane >> 4) + 4 * r;
+            if (row < 6 && col == row) { const double sc = 1.0 / (1.0 + sqrt(v[r])); ssc[row] = sc; A.scale[6 * c + row] = sc; }
+        }
+        WAVE_SYNC();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = (lane >> 4) + 4 * r;
+        if (row < 6 && col < 7) {
+            double o = v[r];
+            if (first) o = (col < 6) ? o * ssc[row] * ssc[col] : o * ssc[row];
+            if (col < 6) Ublk[c * 36 + row * 6 + col] = o;
+            else rhsblk[c * 6 + row] = o;
+        }
+    }
+}
+
+// P role: one block per BM_PB points. Phase 1, one thread per point: (first iteration: Jacobi scale of the point and
+// scaling of the Jacobian rows of its observations), E, g, LM diagonal, E^-1 (LDS + global). Phase 2, one thread per
+// observation of the block's points: the observation's 6x3 blocks of Wt and Yt = W E^-1. Gradient-max partial per block.
+constexpr int BM_OB = 8;    // observations of a point handled per register batch
+constexpr int BM_PB = 64;   // points per block
+__device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st, int pb, double* __restrict__ part_gmax,
+                                      double* sEi /* [BM_PB][9] */, double* red) {
+    if (st->done) return;
+    const int m = 6 * A.nc, krows = A.krows;
+    const int tid = threadIdx.x;
+    const int p0 = pb * BM_PB, p1 = min(A.np, p0 + BM_PB);
+    const int p = p0 + tid;
+    double gmax_p = 0;
+    if (tid < BM_PB && p < p1) {
+        const int e0 = A.pobs_start[p], e1 = A.pobs_start[p + 1];
+        if (st->first) {   // Jacobi scaling: columns of the point from its own rows, columns of the cameras from the C kernel
+            double acc[3] = {0, 0, 0};
+            for (int e = e0; e < e1; e++) {
+                const double* Jp = A.J + (size_t)A.pobs_list[e] * 18 + 12;
+#pragma unroll
+                for (int k = 0; k < 3; k++) acc[k] += Jp[k] * Jp[k] + Jp[3 + k] * Jp[3 + k];
+            }
+            double sp[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { sp[k] = 1.0 / (1.0 + sqrt(acc[k])); A.scale[m + 3 * p + k] = sp[k]; }
+            for (int e = e0; e < e1; e++) {
+                const int i = A.pobs_list[e];
+                const double* sc = A.scale + 6 * A.cam_idx[i];
+                double* Jo = A.J + (size_t)i * 18;
+#pragma unroll
+                for (int k = 0; k < 12; k++) Jo[k] *= sc[k % 6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) Jo[12 + k] *= sp[k % 3];
+            }
+        }
+        double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+        for (int eb = e0; eb < e1; eb += BM_OB) {   // index loads, then value loads, then arithmetic: independent loads in flight
+            int oi[BM_OB];
+#pragma unroll
+            for (int u = 0; u < BM_OB; u++) oi[u] = (eb + u < e1) ? A.pobs_list[eb + u] : -1;
+            double jp[BM_OB][6], rr[BM_OB][2];
+#pragma unroll
+            for (int u = 0; u < BM_OB; u++) {
+                if (oi[u] >= 0) {
+                    const double* Jp = A.J + (size_t)oi[u] * 18 + 12;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) jp[u][k] = Jp[k];
+                    rr[u][0] = A.res[2 * oi[u]]; rr[u][1] = A.res[2 * oi[u] + 1];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) jp[u][k] = 0;
+                    rr[u][0] = rr[u][1] = 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BM_OB; u++) {
+                if (oi[u] >= 0) {
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+#pragma unroll
+                        for (int b = 0; b < 3; b++) E[a * 3 + b] += jp[u][a] * jp[u][b] + jp[u][3 + a] * jp[u][3 + b];
+                        gv[a] += jp[u][a] * rr[u][0] + jp[u][3 + a] * rr[u][1];
+                    }
+                }
+            }
+        }
+        const double radius = st->radius;
+        const bool reuse = st->reuse_diag != 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            double dg;
+            if (!reuse) { dg = fmin(fmax(E[a * 3 + a], 1e-6), 1e32); A.diag[m + 3 * p + a] = dg; }
+            else dg = A.diag[m + 3 * p + a];
+            E[a * 3 + a] += dg / radius;
+            gmax_p = fmax(gmax_p, fabs(gv[a] / A.scale[m + 3 * p + a]));
+        }
+        double L[9];
+        bool ok = true;
+        {
+            double d = E[0];
+            ok = ok && (d > 0.0); L[0] = sqrt(d);
+            L[3] = E[3] / L[0]; L[6] = E[6] / L[0];
+            d = E[4] - L[3] * L[3];
+            ok = ok && (d > 0.0); L[4] = sqrt(d);
+            L[7] = (E[7] - L[6] * L[3]) / L[4];
+            d = E[8] - L[6] * L[6] - L[7] * L[7];
+            ok = ok && (d > 0.0); L[8] = sqrt(d);
+        }
+        double Ei[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (!ok) atomicOr(&st->chol_fail, 1);   // the step is invalid: the solve kernel stops, nothing below is used
+        else {
+#pragma unroll
+            for (int cI = 0; cI < 3; cI++) {
+                double q0 = (cI == 0) ? 1.0 : 0.0, q1 = (cI == 1) ? 1.0 : 0.0, q2 = (cI == 2) ? 1.0 : 0.0;
+                q0 = q0 / L[0];
+                q1 = (q1 - L[3] * q0) / L[4];
+                q2 = (q2 - L[6] * q0 - L[7] * q1) / L[8];
+                q2 = q2 / L[8];
+                q1 = (q1 - L[7] * q2) / L[4];
+                q0 = (q0 - L[6] * q2 - L[3] * q1) / L[0];
+                Ei[0 * 3 + cI] = q0; Ei[1 * 3 + cI] = q1; Ei[2 * 3 + cI] = q2;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) { A.Einv[(size_t)p * 9 + k] = Ei[k]; sEi[tid * 9 + k] = Ei[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { A.gp[(size_t)p * 3 + k] = gv[k]; A.Wd[(size_t)m * krows + 3 * p + k] = gv[k]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax_p = fmax(gmax_p, __shfl_xor(gmax_p, o, 64));
+    if (tid == 0) part_gmax[pb] = gmax_p;   // the points of the block live in wavefront 0
+    __syncthreads();                        // E^-1 in LDS, scaled Jacobian rows (first iteration) in global memory
+    // ---- phase 2: K-columns of cameras that do not see a point stay zero (Yt / Wt are cleared once per solve)
+    const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
+    for (int e = eb0 + tid; e < eb1; e += BM_T) {
+        const int flag = A.odup[e];
+        if (flag == 2) continue;   // a later observation of the same (point, camera): folded into the first one
+        const int i = A.pobs_list[e];
+        const int c = A.cam_idx[i], pp = A.pt_idx[i];
+        const double* Jr = A.J + (size_t)i * 18;
+        double jc[12], jp[6];
+#pragma unroll
+        for (int k = 0; k < 12; k++) jc[k] = Jr[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) jp[k] = Jr[12 + k];
+        double w[18];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int b = 0; b < 3; b++) w[a * 3 + b] = jc[a] * jp[b] + jc[6 + a] * jp[3 + b];
+        }
+        if (flag == 1) {
+            for (int e2 = e + 1; e2 < A.pobs_start[pp + 1]; e2++) {
+                const int i2 = A.pobs_list[e2];
+                if (A.cam_idx[i2] != c) continue;
+                const double* J2 = A.J + (size_t)i2 * 18;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int b = 0; b < 3; b++) w[a * 3 + b] += J2[a] * J2[12 + b] + J2[6 + a] * J2[15 + b];
+                }
+            }
+        }
+        const double* Ei = sEi + (pp - p0) * 9;
+        double ei[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) ei[k] = Ei[k];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            double* wp = &A.Wd[(size_t)(6 * c + a) * krows + 3 * pp];
+            double* yp = &A.Yd[(size_t)(6 * c + a) * krows + 3 * pp];
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                wp[b] = w[a * 3 + b];
+                yp[b] = w[a * 3] * ei[0 * 3 + b] + w[a * 3 + 1] * ei[1 * 3 + b] + w[a * 3 + 2] * ei[2 * 3 + b];
+            }
+        }
+    }
+    (void)red;
+}
+
+// blocks [0, cam_blocks): C role; blocks [cam_blocks, cam_blocks + point_blocks): P role
+__global__ __launch_bounds__(BM_T) void k_bam_campoint(BAArgs A, BAGState* st, int cam_blocks, double* Ublk, double* rhsblk,
+                                                       double* part_gmax) {
+    __shared__ double sred[BM_NW * 4 * 64];   // C role: per-wavefront MFMA accumulators; P role: E^-1 of the block's points
+    __shared__ double ssc[8];
+    static_assert(BM_PB * 9 <= BM_NW * 4 * 64, "LDS");
+    if ((int)blockIdx.x < cam_blocks) bam_cam_role(A, st, blockIdx.x, Ublk, rhsblk, sred, ssc);
+    else bam_point_role(A, st, blockIdx.x - cam_blocks, part_gmax, sred, ssc);
+}
+
+// G: Schur contraction  G = Yt^T [Wt | g]  on FP64 MFMA: BG_H blocks per 16x16 tile, one wavefront per K-slice, the slices
+// of a block are summed in slice order through LDS; the solve kernel adds the BG_H partials (fixed summation order).
+constexpr int BG_W = 4, BG_H = 2;
+__global__ __launch_bounds__(64 * BG_W) void k_bam_gemm(BAArgs A, const BAGState* st) {
+    __shared__ double sacc[BG_W * 4 * 64];
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, krows = A.krows, ldw = A.ldw;
+    const int tc = A.tiles_c;
+    const int tile = blockIdx.x / BG_H, half = blockIdx.x % BG_H;
+    const int ti = tile / tc, tj = tile - ti * tc;
+    const int kper = A.kper;   // multiple of 16; BG_H * BG_W * kper >= krows
+    const int k0 = min(krows, (half * BG_W + wv) * kper), k1 = min(krows, k0 + kper);
+    v4d acc = {0, 0, 0, 0};
+    const double* pa = A.Yd + (size_t)(ti * 16 + (lane & 15)) * krows + 4 * (lane >> 4) + k0;
+    const double* pb = A.Wd + (size_t)(tj * 16 + (lane & 15)) * krows + 4 * (lane >> 4) + k0;
+    const int nk = __builtin_amdgcn_readfirstlane((k1 - k0) / 16);
+    int kb = 0;
+    for (; kb + 4 <= nk; kb += 4) {
+        v4d a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a4[u] = *(const v4d*)(pa + 16 * u); b4[u] = *(const v4d*)(pb + 16 * u); }
+        pa += 64; pb += 64;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[u][q], b4[u][q], acc, 0, 0, 0);
+        }
+    }
+    for (; kb < nk; kb++) {
+        const v4d a4 = *(const v4d*)pa, b4 = *(const v4d*)pb;
+        pa += 16; pb += 16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) sacc[(wv * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double g = sacc[r * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < BG_W; w++) g += sacc[(w * 4 + r) * 64 + lane];
+            A.Gpart[((size_t)half * A.gp_rows + ti * 16 + (lane >> 4) + 4 * r) * ldw + tj * 16 + (lane & 15)] = g;
+        }
+    }
+}
+
+// S: loop-top tests, reduced camera system [S | rhs row] in LDS, right-looking Cholesky with the forward substitution
+// folded in as row m (two barriers per column), backward substitution in registers of wavefront 0 -> step_c; rotation
+// constants of the candidate cameras.
+__global__ __launch_bounds__(BM_T) void k_bam_solve(BAArgs A, BAGState* st, const double* __restrict__ part_cost, int nbo,
+                                                    const double* __restrict__ part_gmax, int nbp, const double* __restrict__ Ublk,
+                                                    const double* __restrict__ rhsblk, double* __restrict__ candrot) {
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    __shared__ double red[3 * BM_NW];
+    __shared__ BAGState ss;   // LDS copy of the state: read here, written through to global memory by thread 0
+    __shared__ int sfail;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tx = tid & 15, ty = tid >> 4;
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#define SSTAMP(k) do { if (A.stamps && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); A.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
+    if (tid == 0) { ss = *st; sfail = 0; }
+    __syncthreads();
+    if (ss.done) return;
+    const int nc = A.nc, m = 6 * nc, n = m + 3 * A.np;
+    double* S = dyn; double* dg = dyn + (size_t)(m + 1) * m;   // S: (m+1) x m, row m = right-hand side; dg: 1 / diagonal of L
+    const double* x = A.x + (size_t)ss.cur * n;
+    if (ss.need_eval) {   // block-uniform
+        double xn = 0, g = 0, cs = 0;
+        for (int i = tid; i < n; i += BM_T) xn += x[i] * x[i];
+        for (int i = tid; i < m; i += BM_T) g = fmax(g, fabs(rhsblk[i] / A.scale[i]));
+        for (int i = tid; i < nbp; i += BM_T) g = fmax(g, part_gmax[i]);
+        for (int i = tid; i < nbo; i += BM_T) cs += part_cost[i];
+        xn = wave_sum_f64(xn); cs = wave_sum_f64(cs);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o, 64));
+        if (lane == 0) { red[wid] = xn; red[BM_NW + wid] = cs; red[2 * BM_NW + wid] = g; }
+        __syncthreads();
+        if (tid == 0) {
+            const double c = (red[BM_NW] + red[BM_NW + 1]) + (red[BM_NW + 2] + red[BM_NW + 3]);
+            ss.x_cost = st->x_cost = c;
+            ss.x_norm = st->x_norm = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+            if (ss.iter == 0) ss.initial_cost = st->initial_cost = c;
+            ss.gmax = st->gmax = fmax(fmax(red[2 * BM_NW], red[2 * BM_NW + 1]), fmax(red[2 * BM_NW + 2], red[2 * BM_NW + 3]));
+        }
+    }
+    if (tid == 0) {
+        int term = -1;
+        if (ss.iter >= ss.max_iterations) term = 0;
+        else if (ss.gmax >= 0 && ss.gmax <= 1e-10) term = 2;
+        else if (ss.radius < 1e-32) term = 4;
+        if (term >= 0) { ss.done = st->done = 1; ss.termination = st->termination = term; }
+        st->step_valid = 0;
+    }
+    __syncthreads();
+    if (ss.done) return;
+    SSTAMP(16);
+    // ---- S = blockdiag(U_c) + D2_c - Yt^T Wt (lower triangle), row m = rhs_c - Yt^T g
+    {
+        const double radius = ss.radius;
+        const bool reuse = ss.reuse_diag != 0;
+        for (int a = ty; a <= m; a += 16) {
+            for (int b = tx; b < m && b <= a; b += 16) {
+                double v;
+                if (a < m) v = (a / 6 == b / 6) ? Ublk[(a / 6) * 36 + (a % 6) * 6 + (b % 6)] : 0.0;
+                else v = rhsblk[b];
+                // row m (the right-hand side) takes column m of G: (Yt^T g)[b]
+                const size_t gi = (a < m) ? (size_t)a * A.ldw + b : (size_t)b * A.ldw + m;
+                double g = A.Gpart[gi];
+#pragma unroll
+                for (int h = 1; h < BG_H; h++) g += A.Gpart[(size_t)h * A.gp_rows * A.ldw + gi];
+                if (a == b) {
+                    double d2;
+                    if (!reuse) { d2 = fmin(fmax(v, 1e-6), 1e32); A.diag[a] = d2; }
+                    else d2 = A.diag[a];
+                    v += d2 / radius;
+                }
+                S[(size_t)a * m + b] = v - g;
+            }
+        }
+    }
+    __syncthreads();
+    if (ss.chol_fail) return;   // a point block was not positive definite: invalid step (step_valid stays 0)
+    SSTAMP(17);
+    // Blocked right-looking Cholesky, block = one camera (6 columns). Per block: (a) one thread factors the 6x6 diagonal
+    // block in registers (the only serial chain: 6 x sqrt + reciprocal), (b) one thread per row below solves its 6 entries
+    // against the block (multiplications by the pivot reciprocals), (c) rank-6 update of the trailing lower triangle.
+    // Row m carries the right-hand side, so the forward substitution is part of (b)/(c). dg keeps the pivot reciprocals.
+    for (int jb = 0; jb < nc; jb++) {
+        const int j0 = 6 * jb;
+        if (tid == 0) {
+            double a[21];   // lower triangle, row-major: (i,k) -> i*(i+1)/2 + k
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int k = 0; k <= i; k++) a[i * (i + 1) / 2 + k] = S[(size_t)(j0 + i) * m + j0 + k];
+            }
+            bool ok = true;
+            double r[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const double d = a[j * (j + 1) / 2 + j];
+                ok = ok && (d > 0.0);
+                const double sq = sqrt(d);
+                r[j] = 1.0 / sq;
+                a[j * (j + 1) / 2 + j] = sq;
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) a[i * (i + 1) / 2 + j] *= r[j];
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) {
+#pragma unroll
+                    for (int k = j + 1; k <= i; k++) a[i * (i + 1) / 2 + k] -= a[i * (i + 1) / 2 + j] * a[k * (k + 1) / 2 + j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int k = 0; k <= i; k++) S[(size_t)(j0 + i) * m + j0 + k] = a[i * (i + 1) / 2 + k];
+                dg[j0 + i] = r[i];
+            }
+            if (!ok) sfail = 1;
+        }
+        __syncthreads();
+        if (sfail) break;   // block-uniform
+        {
+            const int i = j0 + 6 + tid;   // rows below the block, row m = right-hand side (at most 6*22 - 6 + 1 < BM_T rows)
+            if (i <= m) {
+                double v[6], Lb[15], r[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) { v[k] = S[(size_t)i * m + j0 + k]; r[k] = dg[j0 + k]; }
+#pragma unroll
+                for (int q = 1; q < 6; q++) {
+#pragma unroll
+                    for (int k = 0; k < q; k++) Lb[q * (q - 1) / 2 + k] = S[(size_t)(j0 + q) * m + j0 + k];
+                }
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    double t = v[q];
+#pragma unroll
+                    for (int k = 0; k < q; k++) t -= v[k] * Lb[q * (q - 1) / 2 + k];
+                    v[q] = t * r[q];
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) S[(size_t)i * m + j0 + k] = v[k];
+            }
+        }
+        __syncthreads();
+        {
+            const int r0 = j0 + 6;                 // first trailing row / column
+            const int nr = m - r0;                 // trailing columns; rows r0..m (nr + 1 rows)
+            const int total = nr * (nr + 1) / 2 + nr;   // lower triangle of the nr x nr block + the right-hand-side row
+            for (int e = tid; e < total; e += BM_T) {
+                int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);   // row of the triangular index, then exact fix-up
+                while ((ii + 1) * (ii + 2) / 2 <= e) ii++;
+                while (ii * (ii + 1) / 2 > e) ii--;
+                int kk = e - ii * (ii + 1) / 2;
+                if (ii >= nr) { ii = nr; kk = e - nr * (nr + 1) / 2; }   // the last nr entries are the right-hand-side row
+                const double* Li = S + (size_t)(r0 + ii) * m + j0;
+                const double* Lk = S + (size_t)(r0 + kk) * m + j0;
+                double acc = S[(size_t)(r0 + ii) * m + r0 + kk];
+#pragma unroll
+                for (int t = 0; t < 6; t++) acc -= Li[t] * Lk[t];
+                S[(size_t)(r0 + ii) * m + r0 + kk] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (sfail) return;
+    SSTAMP(18);
+    if (wid == 0) {
+        // L^T x = y by camera blocks from the last one up, in wavefront 0 (LDS ordering only, no block barrier): every lane
+        // solves the 6x6 triangular block redundantly in registers, then the lanes subtract the block's contribution from the
+        // rows above. Subtraction order per row = descending column index, as in the column-oriented scalar algorithm.
+        double* ys = S + (size_t)m * m;   // row m: y on entry, x on exit
+        for (int jb = nc - 1; jb >= 0; jb--) {
+            const int j0 = 6 * jb;
+            double xb[6], Lb[15], r[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) { xb[q] = ys[j0 + q]; r[q] = dg[j0 + q]; }
+#pragma unroll
+            for (int q = 1; q < 6; q++) {
+#pragma unroll
+                for (int k = 0; k < q; k++) Lb[q * (q - 1) / 2 + k] = S[(size_t)(j0 + q) * m + j0 + k];
+            }
+#pragma unroll
+            for (int q = 5; q >= 0; q--) {
+                double t = xb[q];
+#pragma unroll
+                for (int k = 5; k > q; k--) t -= Lb[k * (k - 1) / 2 + q] * xb[k];
+                xb[q] = t * r[q];
+            }
+            for (int k = lane; k < j0; k += 64) {
+                double acc = ys[k];
+#pragma unroll
+                for (int t = 5; t >= 0; t--) acc -= S[(size_t)(j0 + t) * m + k] * xb[t];
+                ys[k] = acc;
+            }
+            if (lane < 6) {
+                double v = xb[0];
+#pragma unroll
+                for (int t = 1; t < 6; t++) v = (lane == t) ? xb[t] : v;
+                ys[j0 + lane] = v;
+            }
+            WAVE_SYNC();
+        }
+        for (int k = lane; k < m; k += 64) { const double v = -ys[k]; A.step[k] = v; S[k] = v; }   // the LM step is the negated solution
+        WAVE_SYNC();
+        SSTAMP(19);
+        if (lane < nc) {   // candidate cameras and their rotation constants, once per camera instead of once per observation
+            double cx[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cx[k] = x[6 * lane + k] + S[6 * lane + k] * A.scale[6 * lane + k];
+            CamRot cr;
+            cam_rot_setup(cx, cr);
+            double* o = candrot + 16 * lane;
+#pragma unroll
+            for (int k = 0; k < 6; k++) o[k] = cx[k];
+            o[6] = cr.ct; o[7] = cr.st; o[8] = cr.ti; o[9] = cr.w0; o[10] = cr.w1; o[11] = cr.w2; o[12] = (double)cr.big;
+        }
+        if (lane == 0) st->step_valid = 1;
+        SSTAMP(20);
+    }
+#undef SSTAMP
+}
+
+// B: one block per BM_PB points. Phase A, per observation: Jp^T (Jc y_c); phase B, per point: back-substitution and the
+// candidate point; phase C, per observation: model-cost-change and candidate-cost terms. Partials per block, fixed order.
+__global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* st, const double* __restrict__ candrot,
+                                                      double* __restrict__ tmp3, double* __restrict__ part4) {
+    __shared__ double red[3 * BM_NW];
+    __shared__ double sP[BM_PB * 6];   // per point of the block: step (3), candidate point (3)
+    if (st->done || !st->step_valid) return;
+    const int tid = threadIdx.x;
+    const int nc = A.nc, m = 6 * nc, n = m + 3 * A.np;
+    const double* x = A.x + (size_t)st->cur * n;
+    double* cand = A.x + (size_t)(st->cur ^ 1) * n;
+    const int p0 = blockIdx.x * BM_PB, p1 = min(A.np, p0 + BM_PB);
+    const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
+    double mc = 0, cc = 0, dn2 = 0;
+    for (int e = eb0 + tid; e < eb1; e += BM_T) {
+        const int i = A.pobs_list[e];
+        const int c = A.cam_idx[i];
+        const double* Jr = A.J + (size_t)i * 18;
+        double jy0 = 0, jy1 = 0;   // y_c = -step_c
+#pragma unroll
+        for (int a = 0; a < 6; a++) { const double yc = -A.step[6 * c + a]; jy0 += Jr[a] * yc; jy1 += Jr[6 + a] * yc; }
+#pragma unroll
+        for (int a = 0; a < 3; a++) tmp3[(size_t)e * 3 + a] = Jr[12 + a] * jy0 + Jr[15 + a] * jy1;
+    }
+    __syncthreads();
+    const int p = p0 + tid;
+    if (tid < BM_PB && p < p1) {
+        double t3[3] = {A.gp[(size_t)p * 3], A.gp[(size_t)p * 3 + 1], A.gp[(size_t)p * 3 + 2]};
+        for (int e = A.pobs_start[p]; e < A.pobs_start[p + 1]; e++) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) t3[a] -= tmp3[(size_t)e * 3 + a];
+        }
+        const double* Ei = A.Einv + (size_t)p * 9;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double sp = -(Ei[a * 3] * t3[0] + Ei[a * 3 + 1] * t3[1] + Ei[a * 3 + 2] * t3[2]);
+            A.step[m + 3 * p + a] = sp;
+            const double d = sp * A.scale[m + 3 * p + a];
+            const double xp = x[m + 3 * p + a] + d;
+            cand[m + 3 * p + a] = xp;
+            sP[tid * 6 + a] = sp; sP[tid * 6 + 3 + a] = xp;
+            dn2 += d * d;
+        }
+    }
+    __syncthreads();
+    for (int e = eb0 + tid; e < eb1; e += BM_T) {
+        const int i = A.pobs_list[e];
+        const int c = A.cam_idx[i], pl = A.pt_idx[i] - p0;
+        const double* Jr = A.J + (size_t)i * 18;
+        double sc[6], sp[3], xp[3];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sc[k] = A.step[6 * c + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { sp[k] = sP[pl * 6 + k]; xp[k] = sP[pl * 6 + 3 + k]; }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            double mr = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) mr += Jr[rr * 6 + k] * sc[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) mr += Jr[12 + rr * 3 + k] * sp[k];
+            mc -= mr * (A.res[2 * i + rr] + mr / 2.0);
+        }
+        const double* o = candrot + 16 * c;
+        CamRot cr;
+        cr.ct = o[6]; cr.st = o[7]; cr.ti = o[8]; cr.w0 = o[9]; cr.w1 = o[10]; cr.w2 = o[11]; cr.big = (int)o[12];
+        double r[2];
+        projection_residual_pre(cr, o, xp, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, nullptr, nullptr, false);
+        double rho0, rho1;
+        huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
+        cc += 0.5 * rho0;
+    }
+    if (blockIdx.x == 0) {   // camera part of the candidate and of the step norm
+        for (int i = tid; i < m; i += BM_T) {
+            const double d = A.step[i] * A.scale[i];
+            cand[i] = x[i] + d;
+            dn2 += d * d;
+        }
+    }
+    mc = wave_sum_f64(mc); cc = wave_sum_f64(cc); dn2 = wave_sum_f64(dn2);
+    if ((tid & 63) == 0) { red[tid >> 6] = mc; red[BM_NW + (tid >> 6)] = cc; red[2 * BM_NW + (tid >> 6)] = dn2; }
+    __syncthreads();
+    if (tid == 0) {
+        part4[blockIdx.x * 4] = (red[0] + red[1]) + (red[2] + red[3]);
+        part4[blockIdx.x * 4 + 1] = (red[BM_NW] + red[BM_NW + 1]) + (red[BM_NW + 2] + red[BM_NW + 3]);
+        part4[blockIdx.x * 4 + 2] = (red[2 * BM_NW] + red[2 * BM_NW + 1]) + (red[2 * BM_NW + 2] + red[2 * BM_NW + 3]);
+    }
+}
+
+// F: decision on the last step, results
+__global__ __launch_bounds__(BM_T) void k_bam_finish(BAArgs A, const BAGState* __restrict__ st_in, const double* __restrict__ part4, int nbp) {
+    __shared__ BAGState ss;
+    if (threadIdx.x == 0) {
+        ss = *st_in;
+        if (!ss.done) bam_decide(ss, part4, nbp);
+    }
+    __syncthreads();
+    const int n = 6 * A.nc + 3 * A.np;
+    const double* x = A.x + (size_t)ss.cur * n;
+    for (int i = threadIdx.x; i < 6 * A.nc; i += BM_T) A.cams[i] = x[i];
+    for (int i = threadIdx.x; i < 3 * A.np; i += BM_T) A.pts[i] = x[6 * A.nc + i];
+    if (threadIdx.x == 0) {
+        A.summary[0] = ss.initial_cost; A.summary[1] = ss.x_cost; A.summary[2] = ss.iter; A.summary[3] = ss.successful;
+        A.summary[4] = ss.termination;
+    }
+}
+
+hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double* d_part) {
+    BAGState* st2[2] = {(BAGState*)d_state, (BAGState*)((char*)d_state + 256)};   // double-buffered state
+    static_assert(sizeof(BAGState) <= 256, "BAGState");
+    const int nbo = (A.nobs + BM_T - 1) / BM_T, nbp = (A.np + BM_PB - 1) / BM_PB, m = 6 * A.nc;
+    double* part_cost = d_part;                 // nbo
+    double* part_gmax = part_cost + nbo;        // nbp
+    double* part4 = part_gmax + nbp;            // nbp * 4
+    double* Ublk = part4 + 4 * nbp;             // nc * 36
+    double* rhsblk = Ublk + 36 * A.nc;          // nc * 6
+    double* candrot = rhsblk + 6 * A.nc;        // nc * 16
+    double* tmp3 = candrot + 16 * A.nc;         // nobs * 3
+    const size_t shm = ((size_t)(m + 1) * m + (size_t)m) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_bam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    // Yt and [Wt | g] are adjacent: one clear (columns of cameras that do not see a point are never written)
+    hipError_t e = hipMemsetAsync(A.Yd, 0, 2 * (size_t)A.krows * A.ldw * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    ProfScope ps(K_BA_LM, s);
+    const int tiles = A.tiles_r * A.tiles_c;
+    for (int it = 0; it < A.max_iterations; it++) {
+        BAGState* sin = st2[it & 1];
+        BAGState* sc = st2[(it + 1) & 1];   // the state of this iteration
+        hipLaunchKernelGGL(k_bam_eval, dim3(nbo), dim3(BM_T), 0, s, A, sin, sc, part4, nbp, it, part_cost);
+        if (it == 0) {   // the point kernel needs the camera scales of the C kernel in the first iteration
+            hipLaunchKernelGGL(k_bam_campoint, dim3(A.nc), dim3(BM_T), 0, s, A, sc, A.nc, Ublk, rhsblk, part_gmax);
+            hipLaunchKernelGGL(k_bam_campoint, dim3(nbp), dim3(BM_T), 0, s, A, sc, 0, Ublk, rhsblk, part_gmax);
+        } else
+            hipLaunchKernelGGL(k_bam_campoint, dim3(A.nc + nbp), dim3(BM_T), 0, s, A, sc, A.nc, Ublk, rhsblk, part_gmax);
+        hipLaunchKernelGGL(k_bam_gemm, dim3(tiles * BG_H), dim3(64 * BG_W), 0, s, A, sc);
+        hipLaunchKernelGGL(k_bam_solve, dim3(1), dim3(BM_T), shm, s, A, sc, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot);
+        hipLaunchKernelGGL(k_bam_backsub, dim3(nbp), dim3(BM_T), 0, s, A, sc, candrot, tmp3, part4);
+    }
+    hipLaunchKernelGGL(k_bam_finish, dim3(1), dim3(BM_T), 0, s, A, st2[A.max_iterations & 1], part4, nbp);
+    return hipGetLastError();
 }
 
 hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,
