@@ -216,7 +216,7 @@ def main():
         "kernels": kern,
         "pipeline_stats": {k: st[k] for k in ("lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls",
                                               "ba_obs", "ba_points", "heuristic_motion", "n_landmarks")},
-        "host_stage_seconds_per_step": {k: round(st[k], 4) for k in ("t_lk", "t_detect", "t_pnp", "t_tri", "t_ba", "t_pnp_kernel", "t_ba_kernel")},
+        "host_stage_seconds_per_step": {k: round(st[k], 4) for k in ("t_lk", "t_detect", "t_pnp", "t_tri", "t_ba", "t_pnp_kernel", "t_ba_kernel", "t_tri_essential", "t_tri_pose", "tri_hypotheses")},
         "trajectory_error_m": {"mean": round(float(terr.mean()), 3), "max": round(float(terr.max()), 3),
                                "travelled": round(float(np.linalg.norm(g[-1])), 1)},
         "input_generation_s": round(t_gen, 2),

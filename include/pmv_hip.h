@@ -12,6 +12,7 @@
  *                                          Frame.cpp:58-86,119-138)                      -> BaseFeatureExtractor.h:21
  *   pmv_lk_track                           cv::calcOpticalFlowPyrLK                      (OpenCVLucasKanadeFM.cpp:15) -> BaseFeatureMatcher.h:22
  *   pmv_pnp_ransac                         cv::solvePnPRansac                            (OpenCVEPnPSolver.cpp:35-36) -> BasePnPSolver.h:19
+ *   pmv_triangulate_candidates             cv::recoverPose (triangulation + cheirality)  (OpenCVFivePointTri.cpp:27) -> BaseTriangulator.h
  *   pmv_ba_residuals / pmv_ba_solve        ProjectionResidual + ceres::Solve             (ProjectionResidual.h:38-58,
  *                                          CeresBundleAdjustment.cpp:50-61)              -> BaseOptimizer.h:15
  *
@@ -109,6 +110,15 @@ int pmv_ba_residuals(pmv_ctx* ctx, const double* cams, int nc, const double* pts
 int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
                  const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations,
                  pmv_ba_summary* summary);
+
+/* ---- two-view triangulation ------------------------------------------------------------------ */
+/* The per-point part of cv::recoverPose(E, p1, p2, K, R, t, HUGE_VAL, mask, tri) (OpenCVFivePointTri.cpp:27): for each of
+ * the four (R, t) candidates of decomposeEssentialMat, DLT-triangulate every correspondence (cv::triangulatePoints) and apply
+ * the cheirality tests. q1, q2: n normalised image points (x, y) each; P1x4: four row-major 3x4 matrices [R | t];
+ * mask_in: n bytes (RANSAC inlier mask of findEssentialMat). out_Q: [4][4][n] homogeneous points, out_mask: [4][n],
+ * out_good: [4] number of points passing all tests. n <= max_tracks. */
+int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4,
+                               const uint8_t* mask_in, double* out_Q, uint8_t* out_mask, int* out_good);
 
 /* ---- per-kernel timing (HIP events on the launching stream; used by bench.py for the roofline object) -------------- */
 int pmv_prof_enable(pmv_ctx* ctx, int on);  /* on != 0: reset counters and start recording; 0: stop */

@@ -148,6 +148,11 @@ int orc_host_ba_schedule(int bundle_size, int src_frame, int* win_first, int* wi
     *win_first = first; *win_count = cnt;
     return trig;
 }
+// the per-point part of cv::recoverPose (OpenCVFivePointTri.cpp:27): the checker for pmv_triangulate_candidates
+void orc_triangulate_candidates(const double* q1, const double* q2, int n, const double* P1x4, const unsigned char* mask_in, double* out_Q,
+                                unsigned char* out_mask, int* out_good) {
+    vo::dlt_candidates_host(q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good);
+}
 void orc_host_project_point(const double* R, const double* t, const double* camera, const double* p3, double* p2) {
     vo::Feature3D::projectPoint(R, t, camera, p3, p2);
 }

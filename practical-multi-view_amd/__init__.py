@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
     "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frame_get_level", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
-    "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_ba_residuals", "pmv_ba_solve",
+    "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates",
     "pmv_prof_enable", "pmv_prof_kernel_count", "pmv_prof_kernel_name", "pmv_prof_read",
     "pmv_pipeline_run", "pmv_pipeline_free", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
     "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_get_stats",
@@ -52,7 +52,7 @@ class PipelineParams(C.Structure):
 
 STAT_KEYS = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
              "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale", "t_lk", "t_detect", "t_pnp", "t_tri",
-             "t_ba", "t_pnp_kernel", "t_ba_kernel"]
+             "t_ba", "t_pnp_kernel", "t_ba_kernel", "t_tri_essential", "t_tri_pose", "tri_hypotheses"]
 
 
 class PipelineResult:
@@ -281,6 +281,20 @@ class Context:
                                        _p(obs, _f64p), _p(ci, _i32p), _p(pi, _i32p), obs.shape[0], _p(Kd, _f64p),
                                        C.c_double(huber), max_iterations, C.byref(s)))
         return cams, pts, s
+
+    def triangulate_candidates(self, q1, q2, P1x4, mask_in):
+        """DLT triangulation + cheirality of cv::recoverPose's four candidates: returns Q (4,4,n), mask (4,n), good (4,)"""
+        q1 = np.ascontiguousarray(q1, np.float64).reshape(-1, 2)
+        q2 = np.ascontiguousarray(q2, np.float64).reshape(-1, 2)
+        n = q1.shape[0]
+        P = np.ascontiguousarray(P1x4, np.float64).reshape(48)
+        mi = np.ascontiguousarray(mask_in, np.uint8).reshape(n)
+        Q = np.zeros((4, 4, n), np.float64)
+        mask = np.zeros((4, n), np.uint8)
+        good = np.zeros(4, np.int32)
+        self._ck(self.lib.pmv_triangulate_candidates(self.h, _p(q1, _f64p), _p(q2, _f64p), n, _p(P, _f64p), _p(mi, _u8p),
+                                                     _p(Q, _f64p), _p(mask, _u8p), _p(good, _i32p)))
+        return Q, mask, good
 
     # ---- per-kernel HIP-event timing ----
     def prof_enable(self, on=True):

@@ -25,6 +25,9 @@ hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A);
 hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double* d_part);
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
-                      double* d_rt_out, int* d_inliers, int* d_info);
+                      double* d_rt_out, int* d_inliers, int* d_info, unsigned long long* d_stamps /* diagnostic, may be null */);
+
+hipError_t launch_tri_dlt(hipStream_t s, const double* d_P1x4, const double* d_q1, const double* d_q2, const uint8_t* d_mask_in, int n,
+                          double* d_Q, uint8_t* d_mask);
 
 }  // namespace pmv

@@ -23,6 +23,8 @@ struct BackendBuffers {
     unsigned long long* d_stamps = nullptr;
     void* d_bastate = nullptr;
     double* d_bapart = nullptr;
+    char *d_tri_in = nullptr, *d_tri_out = nullptr;
+    size_t tri_in_bytes = 0, tri_out_bytes = 0;
     // single-copy transfers: one pinned staging block and one device block per direction
     void* h_stage = nullptr;
     size_t h_stage_bytes = 0;
@@ -79,7 +81,12 @@ int backend_create(pmv_ctx* c) {
     b->pnp_out_bytes = 48 + 16 + mt * 4 + 64;
     CKB(hipMalloc(&b->d_pnp_in, b->pnp_in_bytes));
     CKB(hipMalloc(&b->d_pnp_out, b->pnp_out_bytes));
+    b->tri_in_bytes = 48 * 8 + mt * 32 + mt + 64;
+    b->tri_out_bytes = mt * 16 * 8 + mt * 4 + 64;
+    CKB(hipMalloc(&b->d_tri_in, b->tri_in_bytes));
+    CKB(hipMalloc(&b->d_tri_out, b->tri_out_bytes));
     b->h_stage_bytes = std::max(b->h_stage_bytes, std::max(b->ba_io_bytes, b->pnp_in_bytes + b->pnp_out_bytes));
+    b->h_stage_bytes = std::max(b->h_stage_bytes, b->tri_in_bytes + b->tri_out_bytes);
     (void)hipHostFree(b->h_stage);
     CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes));
 #undef CKB
@@ -92,7 +99,7 @@ void backend_destroy(pmv_ctx* c) {
     void* ptrs[] = {b->d_cams, b->d_pts, b->d_obs, b->d_K, b->d_cam_idx, b->d_pt_idx, b->d_pobs_start, b->d_pobs_list, b->d_cobs_start,
                     b->d_cobs_list, b->d_x, b->d_cand, b->d_scale, b->d_diag, b->d_D2, b->d_step, b->d_res, b->d_J, b->d_Einv, b->d_gp,
                     b->d_Yd, b->d_Wd, b->d_S, b->d_rhs, b->d_Gpart, b->d_summary, b->d_obj, b->d_img, b->d_samples, b->d_counts,
-                    b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out, b->d_bastate, b->d_bapart};
+                    b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out, b->d_bastate, b->d_bapart, b->d_tri_in, b->d_tri_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     delete b;
@@ -170,7 +177,7 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     int* d_inl = (int*)(b->d_pnp_out + 64);
     const float thr = (float)((double)reproj_err * (double)reproj_err);
     CKC(launch_pnp(s, d_obj, d_img, m, d_K, d_samples, iterations, thr, confidence, b->d_models, b->d_masks, b->d_counts,
-                   d_rt, d_inl, d_info));
+                   d_rt, d_inl, d_info, getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr));
     char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
     CKC(hipMemcpyAsync(ho, b->d_pnp_out, 64 + (size_t)m * 4, hipMemcpyDeviceToHost, s));
     CKC(hipStreamSynchronize(s));
@@ -359,6 +366,45 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     if (summary) {
         summary->initial_cost = h_out[0]; summary->final_cost = h_out[1]; summary->iterations = (int)h_out[2];
         summary->successful_steps = (int)h_out[3]; summary->termination = (int)h_out[4];
+    }
+    return PMV_OK;
+}
+
+// the per-point part of cv::recoverPose (OpenCVFivePointTri.cpp:27): DLT triangulation + cheirality for the four candidates
+int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,
+                               double* out_Q, uint8_t* out_mask, int* out_good) {
+    REQ(ctx && q1 && q2 && P1x4 && mask_in && out_Q && out_mask && out_good, PMV_ERR_INVALID, "pmv_triangulate_candidates: null argument");
+    REQ(n >= 1 && n <= ctx->max_tracks, PMV_ERR_CAPACITY, "pmv_triangulate_candidates: n=%d (1..max_tracks=%d)", n, ctx->max_tracks);
+    tl_prof = &ctx->prof;
+    CKC(hipSetDevice(ctx->device));
+    BackendBuffers* b = ctx->be;
+    hipStream_t s = ctx->s_back;
+    char* hs = (char*)b->h_stage;
+    // pinned in-block [P1x4 48 | q1 2n | q2 2n | mask n bytes], out-block [Q 16n doubles | mask 4n bytes]
+    double* h_P = (double*)hs;
+    double* h_q1 = h_P + 48;
+    double* h_q2 = h_q1 + (size_t)2 * n;
+    uint8_t* h_m = (uint8_t*)(h_q2 + (size_t)2 * n);
+    const size_t in_bytes = (48 + (size_t)4 * n) * 8 + (size_t)n;
+    memcpy(h_P, P1x4, 48 * 8); memcpy(h_q1, q1, (size_t)n * 16); memcpy(h_q2, q2, (size_t)n * 16); memcpy(h_m, mask_in, (size_t)n);
+    CKC(hipMemcpyAsync(b->d_tri_in, hs, in_bytes, hipMemcpyHostToDevice, s));
+    const double* d_P = (const double*)b->d_tri_in;
+    const double* d_q1 = d_P + 48;
+    const double* d_q2 = d_q1 + (size_t)2 * n;
+    const uint8_t* d_m = (const uint8_t*)(d_q2 + (size_t)2 * n);
+    double* d_Q = (double*)b->d_tri_out;
+    uint8_t* d_mask = (uint8_t*)(d_Q + (size_t)16 * n);
+    CKC(launch_tri_dlt(s, d_P, d_q1, d_q2, d_m, n, d_Q, d_mask));
+    char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
+    const size_t out_bytes = (size_t)16 * n * 8 + (size_t)4 * n;
+    CKC(hipMemcpyAsync(ho, b->d_tri_out, out_bytes, hipMemcpyDeviceToHost, s));
+    CKC(hipStreamSynchronize(s));
+    memcpy(out_Q, ho, (size_t)16 * n * 8);
+    memcpy(out_mask, ho + (size_t)16 * n * 8, (size_t)4 * n);
+    for (int c = 0; c < 4; c++) {
+        int g = 0;
+        for (int i = 0; i < n; i++) g += out_mask[(size_t)c * n + i];
+        out_good[c] = g;
     }
     return PMV_OK;
 }

@@ -73,6 +73,13 @@ struct HipPnP : EPnPSolverBase {
         return n > 0;
     }
 };
+struct HipTri : vo::FivePointTri {   // five-point RANSAC on the host, the per-point DLT + cheirality of recoverPose on the GPU
+    pmv_ctx* ctx;
+    void dlt_candidates(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
+                        uint8_t* out_mask, int* out_good) override {
+        ck(ctx, pmv_triangulate_candidates(ctx, q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good));
+    }
+};
 struct HipBA : BundleAdjustmentBase {
     pmv_ctx* ctx;
     void ba_solve(double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx, const int* pt_idx, int n_obs,
@@ -108,7 +115,7 @@ int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K
         run.owned_ex.push_back(ex);
         auto* lk = new HipLK(); lk->ctx = ctx;
         auto* pnp = new HipPnP(); pnp->ctx = ctx; pnp->tracker = &run.pipe;
-        auto* tri = new vo::FivePointTri(); tri->tracker = &run.pipe;
+        auto* tri = new HipTri(); tri->ctx = ctx; tri->tracker = &run.pipe;
         auto* ba = new HipBA(); ba->ctx = ctx; ba->tracker = &run.pipe;
         run.m = lk; run.p = pnp; run.tr = tri; run.b = ba;
         run.pipe.extractor = ex; run.pipe.matcher = lk; run.pipe.pnpsolver = pnp; run.pipe.triangulator = tri; run.pipe.ba = ba;

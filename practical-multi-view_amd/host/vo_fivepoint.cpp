@@ -13,6 +13,7 @@
 #include <cfloat>
 #include <thread>
 
+#include <chrono>
 namespace vo {
 namespace {
 
@@ -273,7 +274,7 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) 
 
 // cv::findEssentialMat(points1, points2, K, RANSAC, prob, threshold, mask): returns false when no model was found
 bool find_essential_mat(const double* p1, const double* p2, int n, const double* K, double prob, double threshold,
-                        double* E, std::vector<uint8_t>& mask) {
+                        double* E, std::vector<uint8_t>& mask, int* samples_drawn = nullptr) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     std::vector<double> q1(2 * n), q2(2 * n);
     for (int i = 0; i < n; i++) {
@@ -311,6 +312,7 @@ bool find_essential_mat(const double* p1, const double* p2, int n, const double*
         return true;
     }
     for (int iter = 0; iter < niters; iter++) {
+        if (samples_drawn) ++*samples_drawn;
         int idx[5];
         for (int i = 0; i < modelPoints;) {
             int idx_i;
@@ -334,8 +336,8 @@ bool find_essential_mat(const double* p1, const double* p2, int n, const double*
 }
 
 // cv::recoverPose(E, points1, points2, K, R, t, distanceThresh = HUGE_VAL, mask (in/out), triangulatedPoints 4xN)
-int recover_pose(const double* E, const double* p1, const double* p2, int n, const double* K, double* R_out, double* t_out,
-                 std::vector<uint8_t>& mask, std::vector<double>& tri4) {
+int recover_pose(FivePointTri* self, const double* E, const double* p1, const double* p2, int n, const double* K, double* R_out,
+                 double* t_out, std::vector<uint8_t>& mask, std::vector<double>& tri4) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     std::vector<double> q1(2 * n), q2(2 * n);
     for (int i = 0; i < n; i++) {
@@ -355,14 +357,32 @@ int recover_pose(const double* E, const double* p1, const double* p2, int n, con
     const double tv[3] = {U[2], U[5], U[8]};
     const double* Rs[4] = {R1, R2, R1, R2};
     const double tsgn[4] = {1, 1, -1, -1};
-    std::vector<std::vector<uint8_t>> masks(4, std::vector<uint8_t>(n, 0));
-    std::vector<std::vector<double>> tris(4, std::vector<double>((size_t)4 * n));
+    double P1x4[48];
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) P1x4[c * 12 + i * 4 + j] = Rs[c][i * 3 + j]; P1x4[c * 12 + i * 4 + 3] = tsgn[c] * tv[i]; }
+    std::vector<double> Q((size_t)16 * n);
+    std::vector<uint8_t> masks((size_t)4 * n);
     int good[4] = {0, 0, 0, 0};
-    // the four (R, t) hypotheses are independent: one host thread each (cv::recoverPose evaluates them one after another)
+    // the four (R, t) candidates (cv::recoverPose evaluates them one after another) go through the kernel hook
+    self->dlt_candidates(q1.data(), q2.data(), n, P1x4, mask.data(), Q.data(), masks.data(), good);
+    int sel;
+    if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) sel = 0;
+    else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) sel = 1;
+    else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) sel = 2;
+    else sel = 3;
+    memcpy(R_out, Rs[sel], 9 * sizeof(double));
+    for (int i = 0; i < 3; i++) t_out[i] = tsgn[sel] * tv[i];
+    mask.assign(masks.begin() + (size_t)sel * n, masks.begin() + (size_t)(sel + 1) * n);
+    tri4.assign(Q.begin() + (size_t)sel * 4 * n, Q.begin() + (size_t)(sel + 1) * 4 * n);
+    return good[sel];
+}
+
+void dlt_candidates_host(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
+                         uint8_t* out_mask, int* out_good) {
     auto eval_combo = [&](int c) {
-        double P1[12];
-        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) P1[i * 4 + j] = Rs[c][i * 3 + j]; P1[i * 4 + 3] = tsgn[c] * tv[i]; }
+        const double* P1 = P1x4 + 12 * c;
         const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        int good = 0;
         for (int i = 0; i < n; i++) {
             // cvTriangulatePoints: 4x4 DLT, solution = right singular vector of the smallest singular value
             double A[16];
@@ -381,19 +401,20 @@ int recover_pose(const double* E, const double* p1, const double* p2, int n, con
                     AtA[a * 4 + b] = acc;
                 }
             vmath::jacobi_eig(AtA, 4, w4, V4);
-            double Qh[4] = {V4[0], V4[4], V4[8], V4[12]};
-            for (int k = 0; k < 4; k++) tris[c][(size_t)k * n + i] = Qh[k];
+            const double Qh[4] = {V4[0], V4[4], V4[8], V4[12]};
+            for (int k = 0; k < 4; k++) out_Q[((size_t)c * 4 + k) * n + i] = Qh[k];
             bool m = Qh[2] * Qh[3] > 0;
             const double Qn[4] = {Qh[0] / Qh[3], Qh[1] / Qh[3], Qh[2] / Qh[3], Qh[3] / Qh[3]};
             m = m && (Qn[2] < HUGE_VAL);
             const double z2 = P1[8] * Qn[0] + P1[9] * Qn[1] + P1[10] * Qn[2] + P1[11] * Qn[3];
             m = m && (z2 > 0) && (z2 < HUGE_VAL);
-            m = m && mask[i];
-            masks[c][i] = m ? 1 : 0;
-            good[c] += m ? 1 : 0;
+            m = m && mask_in[i];
+            out_mask[(size_t)c * n + i] = m ? 1 : 0;
+            good += m ? 1 : 0;
         }
+        out_good[c] = good;
     };
-    if (n >= 64) {
+    if (n >= 64) {   // the candidates are independent: one host thread each
         std::thread th[3];
         for (int c = 1; c < 4; c++) th[c - 1] = std::thread(eval_combo, c);
         eval_combo(0);
@@ -401,16 +422,6 @@ int recover_pose(const double* E, const double* p1, const double* p2, int n, con
     } else {
         for (int c = 0; c < 4; c++) eval_combo(c);
     }
-    int sel;
-    if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) sel = 0;
-    else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) sel = 1;
-    else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) sel = 2;
-    else sel = 3;
-    memcpy(R_out, Rs[sel], 9 * sizeof(double));
-    for (int i = 0; i < 3; i++) t_out[i] = tsgn[sel] * tv[i];
-    mask = masks[sel];
-    tri4 = tris[sel];
-    return good[sel];
 }
 
 // ---- OpenCVFivePointTri.cpp:5-54 ---------------------------------------------------------------------------------
@@ -431,14 +442,20 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     std::vector<uint8_t> mask;
     std::vector<double> tri;
     double E[9];
-    const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask);
+    int drawn = 0;
+    auto tE = std::chrono::steady_clock::now();
+    const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn);
+    tracker->stats.t_tri_essential += std::chrono::duration<double>(std::chrono::steady_clock::now() - tE).count();
+    tracker->stats.tri_hypotheses += drawn;
     if (!ok) {
         // cv::recoverPose on an empty E raises in the reference (uncaught). Keep the pipeline alive: no motion, no landmarks.
         R_out = Mat3::eye();
         t_out = Vec3{{0, 0, 0}};
         return;
     }
-    recover_pose(E, p1.data(), p2.data(), n, tracker->camera, R_out.m, t_out.v, mask, tri);
+    auto tP = std::chrono::steady_clock::now();
+    recover_pose(this, E, p1.data(), p2.data(), n, tracker->camera, R_out.m, t_out.v, mask, tri);
+    tracker->stats.t_tri_pose += std::chrono::duration<double>(std::chrono::steady_clock::now() - tP).count();
     const Vec3& g1 = tracker->gt_t[j + tracker->init_offset + 1];
     const Vec3& g0 = tracker->gt_t[j + tracker->init_offset];
     const double d0 = g1.v[0] - g0.v[0], d1 = g1.v[1] - g0.v[1], d2 = g1.v[2] - g0.v[2];

@@ -60,10 +60,22 @@ public:
                             std::vector<int>& inliers) = 0;
     void solvePnP(Frame& src, Frame& next, Mat3& R, Vec3& t) override;
 };
-class FivePointTri : public BaseTriangulator {                   // OpenCVFivePointTri (host)
+// The per-point part of cv::recoverPose: for each of the four (R, t) candidates of an essential matrix, DLT-triangulate
+// every correspondence (cvTriangulatePoints: eigenvector of the smallest eigenvalue of A^T A, 4x4) and apply the cheirality
+// tests. q1/q2: n normalised image points (x, y); P1x4: four 3x4 camera matrices [R | t]; mask_in: n bytes (RANSAC inliers);
+// out_Q: [candidate][4][n] homogeneous points; out_mask: [candidate][n]; out_good: [4] counts. Host loops (oracle + default).
+void dlt_candidates_host(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
+                         uint8_t* out_mask, int* out_good);
+
+class FivePointTri : public BaseTriangulator {                   // OpenCVFivePointTri
 public:
     OdometryPipeline* tracker = nullptr;
     void triangulate(Frame& src, Frame& next, Mat3& R, Vec3& t) override;
+    // kernel hook (same contract as dlt_candidates_host); the HIP plugin overrides it with pmv_triangulate_candidates
+    virtual void dlt_candidates(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
+                                uint8_t* out_mask, int* out_good) {
+        dlt_candidates_host(q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good);
+    }
 };
 class BundleAdjustmentBase : public BaseOptimizer {              // CeresBundleAdjustment
 public:
@@ -80,6 +92,7 @@ struct Stats {
     long heuristic_motion = 0;
     // wall time per stage as seen by the calling host thread (adapter gather/scatter + plugin kernel + sync)
     double t_lk = 0, t_detect = 0, t_pnp = 0, t_tri = 0, t_ba = 0, t_pnp_kernel = 0, t_ba_kernel = 0;
+    double t_tri_essential = 0, t_tri_pose = 0, tri_hypotheses = 0;   // inside t_tri: five-point RANSAC, recoverPose; RANSAC samples drawn
 };
 
 class OdometryPipeline {

@@ -175,6 +175,21 @@ def ba_solve(cams, pts, obs, cam_idx, pt_idx, K, huber=1.0, max_iterations=5):
                            termination=int(s[4]))
 
 
+def triangulate_candidates(q1, q2, P1x4, mask_in):
+    lib = load().lib
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(-1, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(-1, 2)
+    n = q1.shape[0]
+    P = np.ascontiguousarray(P1x4, np.float64).reshape(48)
+    mi = np.ascontiguousarray(mask_in, np.uint8).reshape(n)
+    Q = np.zeros((4, 4, n), np.float64)
+    mask = np.zeros((4, n), np.uint8)
+    good = np.zeros(4, np.int32)
+    lib.orc_triangulate_candidates(_p(q1, _f64p), _p(q2, _f64p), n, _p(P, _f64p), _p(mi, _u8p), _p(Q, _f64p), _p(mask, _u8p),
+                                   _p(good, _i32p))
+    return Q, mask, good
+
+
 def pnp_ransac(obj, img, K, rvec, tvec, iterations=100, reproj_err=8.0, confidence=0.99):
     lib = load().lib
     o = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)

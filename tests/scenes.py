@@ -69,3 +69,27 @@ def pnp_problem(seed, m=400, outlier_frac=0.2, noise=0.5):
     out = rng.random(m) < outlier_frac
     uv[out] += rng.normal(0, 40, (int(out.sum()), 2)).astype(np.float32)
     return dict(obj=X, img=uv, rvec_true=rtrue, tvec_true=ttrue, outliers=out)
+
+
+def two_view_problem(seed, n=400, outlier_frac=0.15, noise=0.3):
+    """Two views of a point cloud in front of camera 0 = [I|0]; camera 1 = [R|t] with |t| = 1 (essential-matrix scale).
+    Returns normalised image points q1, q2 (n,2), the four candidate matrices of decomposeEssentialMat (true one first:
+    [R|t], [R2|t], [R|-t], [R2|-t]) as (4,3,4), the RANSAC-style inlier mask and the true points."""
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-3, 2, n), rng.uniform(5, 40, n)], 1)
+    rv = rng.normal(0, 0.02, 3)
+    th = np.linalg.norm(rv); k = rv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = np.array([0.05, -0.02, -1.0]); t /= np.linalg.norm(t)
+    Xc = (R @ X.T).T + t
+    q1 = X[:, :2] / X[:, 2:3]
+    q2 = Xc[:, :2] / Xc[:, 2:3]
+    q1 = q1 + rng.normal(0, noise / K[0], q1.shape)
+    q2 = q2 + rng.normal(0, noise / K[0], q2.shape)
+    mask = (rng.random(n) >= outlier_frac).astype(np.uint8)
+    # the "twisted" rotation of decomposeEssentialMat: R2 = R_t(pi) R
+    Rt = 2 * np.outer(t, t) - np.eye(3)
+    R2 = Rt @ R
+    P = np.stack([np.hstack([R, t[:, None]]), np.hstack([R2, t[:, None]]), np.hstack([R, -t[:, None]]), np.hstack([R2, -t[:, None]])])
+    return dict(q1=q1, q2=q2, P1x4=P, mask=mask, X=X)

@@ -110,3 +110,20 @@ def test_pnp_degenerate_inputs(pmv, gpu_ctx_factory):
     rv, tv, inl = ctx.pnp_ransac(obj, img, scenes.K, np.zeros(3), np.zeros(3))
     rr, rt, rinl, _ = ob.pnp_ransac(obj, img, scenes.K, np.zeros(3), np.zeros(3))
     assert len(inl) == len(rinl)
+
+
+@pytest.mark.parametrize("seed,n", [(1, 400), (2, 63), (3, 1), (4, 1500)])
+def test_triangulate_candidates_bit_exact(gpu_ctx_factory, seed, n):
+    """recoverPose's DLT + cheirality on the GPU against the host loops (same operation order): bit-exact."""
+    P = scenes.two_view_problem(seed, n=n)
+    ctx = _ctx(gpu_ctx_factory)
+    Q, mask, good = ctx.triangulate_candidates(P["q1"], P["q2"], P["P1x4"], P["mask"])
+    rQ, rmask, rgood = ob.triangulate_candidates(P["q1"], P["q2"], P["P1x4"], P["mask"])
+    assert np.array_equal(Q, rQ)
+    assert np.array_equal(mask, rmask) and np.array_equal(good, rgood)
+    # KA: the true candidate wins the cheirality vote and its points reproduce the scene up to the noise
+    assert good[0] == max(good) and good[0] >= 0.9 * P["mask"].sum()
+    X = (Q[0, :3] / Q[0, 3]).T
+    ok = mask[0].astype(bool)
+    if ok.sum() > 10:
+        assert np.median(np.linalg.norm(X[ok] - P["X"][ok], axis=1) / P["X"][ok, 2]) < 0.05

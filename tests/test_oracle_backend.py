@@ -157,3 +157,17 @@ def test_feature3d_float32_round_trip_quirk_q7(orc):
     orc.lib.orc_host_f3d_roundtrip(_P(R), _P(t), q.ctypes.data_as(C.POINTER(C.c_float)), 1)
     assert np.abs(q - p).max() < 1e-4 and q.dtype == np.float32
     assert np.abs(q.astype(np.float64) - p).max() <= 64 * np.spacing(np.float32(263.0))
+
+
+def test_dlt_candidates_known_answer():
+    """KA for the checker of pmv_triangulate_candidates: exact two-view geometry -> the true (R, t) candidate passes the
+    cheirality test for every point and the DLT points equal the scene; the mirrored translation fails for every point."""
+    P = scenes.two_view_problem(5, n=200, outlier_frac=0.0, noise=0.0)
+    Q, mask, good = ob.triangulate_candidates(P["q1"], P["q2"], P["P1x4"], P["mask"])
+    assert good[0] == 200 and good[2] == 0
+    X = (Q[0, :3] / Q[0, 3]).T
+    np.testing.assert_allclose(X, P["X"], rtol=1e-7, atol=1e-7)
+    # mask_in gates the output mask (recoverPose: mask &= RANSAC mask)
+    m_in = P["mask"].copy(); m_in[::2] = 0
+    _, mask2, good2 = ob.triangulate_candidates(P["q1"], P["q2"], P["P1x4"], m_in)
+    assert good2[0] == 100 and not mask2[0, ::2].any()
