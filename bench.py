@@ -127,11 +127,13 @@ def main():
         # both pyramids read once + 13 B per track out
         "k_lk": 2.0 * pyr_px + 13.0 * (st["lk_points"] / max(st["lk_calls"], 1)),
         # obj (12 B) + img (8 B) per point in, model out; hypotheses re-read them from L2
-        "k_pnp_hyp": 20.0 * (st["pnp_points"] / max(st["pnp_calls"], 1)) + 100 * 48.0,
-        "k_pnp_score": 20.0 * (st["pnp_points"] / max(st["pnp_calls"], 1)) + 100 * (st["pnp_points"] / max(st["pnp_calls"], 1)),
+        # + one inlier-mask byte per (hypothesis, point)
+        "k_pnp_hyp": 20.0 * (st["pnp_points"] / max(st["pnp_calls"], 1)) + 100 * 48.0 + 100 * (st["pnp_points"] / max(st["pnp_calls"], 1)),
         "k_pnp_select_refit": 20.0 * (st["pnp_points"] / max(st["pnp_calls"], 1)),
         # B_ba = n_obs*(2+2+4+4)*8 B per LM iteration (Jacobians recomputed, not stored)
         "k_ba_lm": 96.0 * (st["ba_obs"] / max(st["ba_calls"], 1)) * wl["ba_iterations"],
+        # two-view DLT: 33 B in, 4 candidates x (32 B point + 1 B mask) out per correspondence (~1.5 x tracks per call)
+        "k_tri_dlt": (33.0 + 132.0) * 1.5 * wl["min_tracked"],
         "k_gftt_eig": float(w * h), "k_gftt_select": 4.0 * w * h,
         "k_pad_level0": (w * h + (w + 128) * (h + 128)) * float(n), "k_pyrdown": 0.0,
     }

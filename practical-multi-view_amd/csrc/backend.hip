@@ -58,7 +58,7 @@ int backend_create(pmv_ctx* c) {
     CKB(hipMalloc(&b->d_res, no * 2 * 8)); CKB(hipMalloc(&b->d_J, no * 18 * 8));
     CKB(hipMalloc(&b->d_Einv, np * 9 * 8)); CKB(hipMalloc(&b->d_gp, np * 3 * 8));
     b->ydwd_elems = krows * ldw;
-    CKB(hipMalloc(&b->d_Yd, 2 * b->ydwd_elems * 8)); CKB(hipMalloc(&b->d_Wd, b->ydwd_elems * 8));
+    CKB(hipMalloc(&b->d_Yd, 2 * b->ydwd_elems * 8));   // Yt | [Wt | g] adjacent: one clear per solve CKB(hipMalloc(&b->d_Wd, b->ydwd_elems * 8));
     CKB(hipMalloc(&b->d_S, m * m * 8)); CKB(hipMalloc(&b->d_rhs, m * 8));
     b->gpart_elems = (size_t)8 * ldw * ldw;   // up to 8 K-slices of an (ldw x ldw) tile grid
     CKB(hipMalloc(&b->d_Gpart, b->gpart_elems * 8));
@@ -281,6 +281,11 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
             odup[e] = earlier ? 2 : (later ? 1 : 0);
         }
     }
+    // launch mode: multi (one launch per LM phase, default) | single (one persistent workgroup); PMV_BA_MODE overrides
+    static const int mode = [] { const char* e = getenv("PMV_BA_MODE"); if (getenv("PMV_BA_SINGLE")) return 0;
+                                 return (e && !strcmp(e, "single")) ? 0 : 1; }();
+    const int m = 6 * nc;
+    const int tiles_r = (m + 15) / 16, tiles_c = (m + 1 + 15) / 16;
     REQ(io_bytes <= b->ba_io_bytes, PMV_ERR_CAPACITY, "pmv_ba_solve: io block too small");
     CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
     char* dio = b->d_ba_io;
@@ -300,26 +305,28 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     A.x = b->d_x; A.cand = b->d_cand; A.scale = b->d_scale; A.diag = b->d_diag; A.D2 = b->d_D2; A.step = b->d_step; A.res = b->d_res; A.J = b->d_J;
     A.Einv = b->d_Einv; A.gp = b->d_gp; A.Yd = b->d_Yd; A.Wd = b->d_Wd; A.S = b->d_S; A.rhs = b->d_rhs; A.Gpart = b->d_Gpart; A.summary = d_sum;
     A.stamps = getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr;
-    const int m = 6 * nc;
-    A.tiles_r = (m + 15) / 16; A.tiles_c = (m + 1 + 15) / 16;
+    A.tiles_r = tiles_r; A.tiles_c = tiles_c;
     A.ldw = A.tiles_c * 16;
     A.krows = round_up(3 * np, 16);
     A.gp_rows = A.tiles_r * 16;
     int ks = 8 / (A.tiles_r * A.tiles_c);
     if (ks < 1) ks = 1;
     if (ks > 8) ks = 8;
-    if (!getenv("PMV_BA_SINGLE")) ks = 8;   // multi-kernel path: one wavefront per (tile, K-slice) anywhere on the chip
+    if (mode != 0) ks = 8;   // multi-kernel paths: one wavefront per (tile, K-slice) anywhere on the chip
     A.kper = round_up((A.krows + ks - 1) / ks, 16);
     A.kslices = (A.krows + A.kper - 1) / A.kper;
     REQ((size_t)A.krows * A.ldw <= b->ydwd_elems && (size_t)A.kslices * A.gp_rows * A.ldw <= b->gpart_elems, PMV_ERR_CAPACITY, "pmv_ba_solve: workspace too small");
     REQ(((size_t)(m + 1) * m + (size_t)m) * 8 <= 150 * 1024, PMV_ERR_CAPACITY, "pmv_ba_solve: %d cameras exceed the LDS-resident reduced system (max 22)", nc);
-    // x holds two parameter vectors (current / candidate) in the multi-kernel solver
-    static const bool single = getenv("PMV_BA_SINGLE") != nullptr;   // A/B switch: the one-workgroup persistent kernel
+    // x holds two parameter vectors (current / candidate) in the multi-kernel solvers
+    const bool single = mode == 0;
     static const bool check = getenv("PMV_BA_CHECK") != nullptr;
     std::vector<char> saved;
     if (check) saved.assign(hs, hs + io_bytes);
     if (single) CKC(launch_ba_lm(s, A));
-    else { A.Wd = A.Yd + (size_t)A.krows * A.ldw; CKC(launch_ba_multi(s, A, b->d_bastate, b->d_bapart)); }
+    else {
+        A.Wd = A.Yd + (size_t)A.krows * A.ldw;
+        CKC(launch_ba_multi(s, A, b->d_bastate, b->d_bapart));
+    }
     const size_t out_bytes = (8 + (size_t)nc * 6 + (size_t)np * 3) * 8;
     CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));
     CKC(hipStreamSynchronize(s));

@@ -798,9 +798,9 @@ __device__ inline void bam_decide(BAGState& s, const double* __restrict__ part4,
 
 // E: decision on the previous step (it > 0), then r and J (Huber-corrected, Jacobi-scaled once the scaling exists) at the
 // current point; one thread per observation; cost partial per block.
-__global__ __launch_bounds__(BM_T) void k_bam_eval(BAArgs A, const BAGState* __restrict__ st_in, BAGState* __restrict__ st_out,
-                                                   const double* __restrict__ part4, int nbp, int it,
-                                                   double* __restrict__ part_cost) {
+__device__ inline void bam_eval_role(const BAArgs& A, const BAGState* __restrict__ st_in, BAGState* __restrict__ st_out,
+                                     const double* __restrict__ part4, int nbp, int it, double* __restrict__ part_cost, int bid,
+                                     int nblk) {
     __shared__ BAGState ss;
     __shared__ double red[BM_NW];
     const int tid = threadIdx.x;
@@ -815,16 +815,16 @@ __global__ __launch_bounds__(BM_T) void k_bam_eval(BAArgs A, const BAGState* __r
             ss = *st_in;
             if (!ss.done) bam_decide(ss, part4, nbp);
         }
-        if (blockIdx.x == 0) *st_out = ss;
+        if (bid == 0) *st_out = ss;
     }
     __syncthreads();
     if (ss.done || !ss.need_eval) return;
     const double* xc; const double* xp;
     if (it == 0) {   // the parameter vector starts as the caller's cameras and points
         xc = A.cams; xp = A.pts;
-        for (int i = blockIdx.x * BM_T + tid; i < n; i += gridDim.x * BM_T) A.x[i] = (i < 6 * A.nc) ? A.cams[i] : A.pts[i - 6 * A.nc];
+        for (int i = bid * BM_T + tid; i < n; i += nblk * BM_T) A.x[i] = (i < 6 * A.nc) ? A.cams[i] : A.pts[i - 6 * A.nc];
     } else { xc = A.x + (size_t)ss.cur * n; xp = xc + 6 * A.nc; }
-    const int i = blockIdx.x * BM_T + tid;
+    const int i = bid * BM_T + tid;
     double cpart = 0;
     if (i < A.nobs) {
         const int c = A.cam_idx[i], p = A.pt_idx[i];
@@ -855,7 +855,12 @@ __global__ __launch_bounds__(BM_T) void k_bam_eval(BAArgs A, const BAGState* __r
     cpart = wave_sum_f64(cpart);
     if ((tid & 63) == 0) red[tid >> 6] = cpart;
     __syncthreads();
-    if (tid == 0) part_cost[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) part_cost[bid] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(BM_T) void k_bam_eval(BAArgs A, const BAGState* st_in, BAGState* st_out, const double* part4, int nbp, int it,
+                                                   double* part_cost) {
+    bam_eval_role(A, st_in, st_out, part4, nbp, it, part_cost, blockIdx.x, gridDim.x);
 }
 
 // C role: one block (4 wavefronts) per camera: U_c (6x6) and rhs_c on FP64 MFMA; in the first iteration also the Jacobi
@@ -1059,24 +1064,29 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
 }
 
 // blocks [0, cam_blocks): C role; blocks [cam_blocks, cam_blocks + point_blocks): P role
+constexpr int BM_WORK = BM_NW * 4 * 64;   // doubles of block-shared scratch: MFMA accumulators per wavefront / E^-1 of a block's points
+__device__ inline void bam_campoint_role(const BAArgs& A, BAGState* st, int cam_blocks, double* Ublk, double* rhsblk, double* part_gmax,
+                                         int bid, double* sred /* [BM_WORK] */) {
+    __shared__ double ssc[8];
+    static_assert(BM_PB * 9 <= BM_WORK, "LDS");
+    if (bid < cam_blocks) bam_cam_role(A, st, bid, Ublk, rhsblk, sred, ssc);
+    else bam_point_role(A, st, bid - cam_blocks, part_gmax, sred, ssc);
+}
 __global__ __launch_bounds__(BM_T) void k_bam_campoint(BAArgs A, BAGState* st, int cam_blocks, double* Ublk, double* rhsblk,
                                                        double* part_gmax) {
-    __shared__ double sred[BM_NW * 4 * 64];   // C role: per-wavefront MFMA accumulators; P role: E^-1 of the block's points
-    __shared__ double ssc[8];
-    static_assert(BM_PB * 9 <= BM_NW * 4 * 64, "LDS");
-    if ((int)blockIdx.x < cam_blocks) bam_cam_role(A, st, blockIdx.x, Ublk, rhsblk, sred, ssc);
-    else bam_point_role(A, st, blockIdx.x - cam_blocks, part_gmax, sred, ssc);
+    __shared__ double swork[BM_WORK];
+    bam_campoint_role(A, st, cam_blocks, Ublk, rhsblk, part_gmax, blockIdx.x, swork);
 }
 
 // G: Schur contraction  G = Yt^T [Wt | g]  on FP64 MFMA: BG_H blocks per 16x16 tile, one wavefront per K-slice, the slices
 // of a block are summed in slice order through LDS; the solve kernel adds the BG_H partials (fixed summation order).
 constexpr int BG_W = 4, BG_H = 2;
-__global__ __launch_bounds__(64 * BG_W) void k_bam_gemm(BAArgs A, const BAGState* st) {
-    __shared__ double sacc[BG_W * 4 * 64];
+__device__ inline void bam_gemm_role(const BAArgs& A, const BAGState* st, int bid, double* sacc /* [BG_W * 4 * 64] */) {
+    static_assert(BG_W * 4 * 64 <= BM_NW * 4 * 64, "LDS");
     if (st->done) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, krows = A.krows, ldw = A.ldw;
     const int tc = A.tiles_c;
-    const int tile = blockIdx.x / BG_H, half = blockIdx.x % BG_H;
+    const int tile = bid / BG_H, half = bid % BG_H;
     const int ti = tile / tc, tj = tile - ti * tc;
     const int kper = A.kper;   // multiple of 16; BG_H * BG_W * kper >= krows
     const int k0 = min(krows, (half * BG_W + wv) * kper), k1 = min(krows, k0 + kper);
@@ -1116,12 +1126,17 @@ __global__ __launch_bounds__(64 * BG_W) void k_bam_gemm(BAArgs A, const BAGState
     }
 }
 
+__global__ __launch_bounds__(64 * BG_W) void k_bam_gemm(BAArgs A, const BAGState* st) {
+    __shared__ double swork[BG_W * 4 * 64];
+    bam_gemm_role(A, st, blockIdx.x, swork);
+}
+
 // S: loop-top tests, reduced camera system [S | rhs row] in LDS, right-looking Cholesky with the forward substitution
 // folded in as row m (two barriers per column), backward substitution in registers of wavefront 0 -> step_c; rotation
 // constants of the candidate cameras.
-__global__ __launch_bounds__(BM_T) void k_bam_solve(BAArgs A, BAGState* st, const double* __restrict__ part_cost, int nbo,
-                                                    const double* __restrict__ part_gmax, int nbp, const double* __restrict__ Ublk,
-                                                    const double* __restrict__ rhsblk, double* __restrict__ candrot) {
+__device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const double* __restrict__ part_cost, int nbo,
+                                      const double* __restrict__ part_gmax, int nbp, const double* __restrict__ Ublk,
+                                      const double* __restrict__ rhsblk, double* __restrict__ candrot) {
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ double red[3 * BM_NW];
     __shared__ BAGState ss;   // LDS copy of the state: read here, written through to global memory by thread 0
@@ -1334,10 +1349,15 @@ __global__ __launch_bounds__(BM_T) void k_bam_solve(BAArgs A, BAGState* st, cons
 #undef SSTAMP
 }
 
+__global__ __launch_bounds__(BM_T) void k_bam_solve(BAArgs A, BAGState* st, const double* part_cost, int nbo, const double* part_gmax,
+                                                    int nbp, const double* Ublk, const double* rhsblk, double* candrot) {
+    bam_solve_role(A, st, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot);
+}
+
 // B: one block per BM_PB points. Phase A, per observation: Jp^T (Jc y_c); phase B, per point: back-substitution and the
 // candidate point; phase C, per observation: model-cost-change and candidate-cost terms. Partials per block, fixed order.
-__global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* st, const double* __restrict__ candrot,
-                                                      double* __restrict__ tmp3, double* __restrict__ part4) {
+__device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, const double* __restrict__ candrot,
+                                        double* __restrict__ tmp3, double* __restrict__ part4, int bid) {
     __shared__ double red[3 * BM_NW];
     __shared__ double sP[BM_PB * 6];   // per point of the block: step (3), candidate point (3)
     if (st->done || !st->step_valid) return;
@@ -1345,7 +1365,7 @@ __global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* 
     const int nc = A.nc, m = 6 * nc, n = m + 3 * A.np;
     const double* x = A.x + (size_t)st->cur * n;
     double* cand = A.x + (size_t)(st->cur ^ 1) * n;
-    const int p0 = blockIdx.x * BM_PB, p1 = min(A.np, p0 + BM_PB);
+    const int p0 = bid * BM_PB, p1 = min(A.np, p0 + BM_PB);
     const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
     double mc = 0, cc = 0, dn2 = 0;
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
@@ -1406,7 +1426,7 @@ __global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* 
         huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
         cc += 0.5 * rho0;
     }
-    if (blockIdx.x == 0) {   // camera part of the candidate and of the step norm
+    if (bid == 0) {   // camera part of the candidate and of the step norm
         for (int i = tid; i < m; i += BM_T) {
             const double d = A.step[i] * A.scale[i];
             cand[i] = x[i] + d;
@@ -1417,14 +1437,18 @@ __global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* 
     if ((tid & 63) == 0) { red[tid >> 6] = mc; red[BM_NW + (tid >> 6)] = cc; red[2 * BM_NW + (tid >> 6)] = dn2; }
     __syncthreads();
     if (tid == 0) {
-        part4[blockIdx.x * 4] = (red[0] + red[1]) + (red[2] + red[3]);
-        part4[blockIdx.x * 4 + 1] = (red[BM_NW] + red[BM_NW + 1]) + (red[BM_NW + 2] + red[BM_NW + 3]);
-        part4[blockIdx.x * 4 + 2] = (red[2 * BM_NW] + red[2 * BM_NW + 1]) + (red[2 * BM_NW + 2] + red[2 * BM_NW + 3]);
+        part4[bid * 4] = (red[0] + red[1]) + (red[2] + red[3]);
+        part4[bid * 4 + 1] = (red[BM_NW] + red[BM_NW + 1]) + (red[BM_NW + 2] + red[BM_NW + 3]);
+        part4[bid * 4 + 2] = (red[2 * BM_NW] + red[2 * BM_NW + 1]) + (red[2 * BM_NW + 2] + red[2 * BM_NW + 3]);
     }
 }
 
+__global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* st, const double* candrot, double* tmp3, double* part4) {
+    bam_backsub_role(A, st, candrot, tmp3, part4, blockIdx.x);
+}
+
 // F: decision on the last step, results
-__global__ __launch_bounds__(BM_T) void k_bam_finish(BAArgs A, const BAGState* __restrict__ st_in, const double* __restrict__ part4, int nbp) {
+__device__ inline void bam_finish_role(const BAArgs& A, const BAGState* __restrict__ st_in, const double* __restrict__ part4, int nbp) {
     __shared__ BAGState ss;
     if (threadIdx.x == 0) {
         ss = *st_in;
@@ -1439,6 +1463,10 @@ __global__ __launch_bounds__(BM_T) void k_bam_finish(BAArgs A, const BAGState* _
         A.summary[0] = ss.initial_cost; A.summary[1] = ss.x_cost; A.summary[2] = ss.iter; A.summary[3] = ss.successful;
         A.summary[4] = ss.termination;
     }
+}
+
+__global__ __launch_bounds__(BM_T) void k_bam_finish(BAArgs A, const BAGState* st_in, const double* part4, int nbp) {
+    bam_finish_role(A, st_in, part4, nbp);
 }
 
 hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double* d_part) {

@@ -1,5 +1,5 @@
-// gfx950 PnP: batched RANSAC hypotheses (5-point EPnP, one wavefront per hypothesis), inlier scoring (hypothesis x point
-// grid), the sequential RANSAC bookkeeping (adaptive iteration cut-off) replayed on the device, and the Levenberg–Marquardt
+// gfx950 PnP: batched RANSAC hypotheses (5-point EPnP, one wavefront per hypothesis, which also scores its model on all
+// points), the sequential RANSAC bookkeeping (adaptive iteration cut-off) replayed on the device, and the Levenberg–Marquardt
 // refit on the inliers — everything cv::solvePnPRansac does behind /root/reference/OpenCVEPnPSolver.cpp:35-36.
 // The sample index stream (cv::RNG((uint64)-1), 5 distinct indices per iteration) depends only on the point count, so the
 // host adapter generates all `iterations` samples up front; evaluating them in parallel and then replaying the
@@ -152,8 +152,10 @@ __device__ double epnp_R_and_t(const EpnpShared& sh, const double* betas, double
 // grid = n_hyp, block = 64. models: n_hyp x 6 (rvec, tvec)
 __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, const float* __restrict__ img,
                                                 const int* __restrict__ samples, const double* __restrict__ K,
-                                                double* __restrict__ models, unsigned long long* stamps) {
+                                                double* __restrict__ models, int m, float thr, uint8_t* __restrict__ masks,
+                                                int* __restrict__ counts, unsigned long long* stamps) {
     __shared__ EpnpShared sh;
+    __shared__ double sR[9], sT[3];
     const int h = blockIdx.x, lane = threadIdx.x;
     unsigned long long t_prev = __builtin_readcyclecounter();
 #define HSTAMP(k) do { if (stamps && h == 0 && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
@@ -381,43 +383,35 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
         if (sh.case_err[2] < sh.case_err[N]) N = 2;
         double rv[3];
         d_rodrigues_m2v(sh.case_R + 9 * N, rv);
-        for (int i = 0; i < 3; i++) { models[h * 6 + i] = rv[i]; models[h * 6 + 3 + i] = sh.case_t[N * 3 + i]; }
+        for (int i = 0; i < 3; i++) { models[h * 6 + i] = rv[i]; models[h * 6 + 3 + i] = sh.case_t[N * 3 + i]; sT[i] = sh.case_t[N * 3 + i]; }
+        d_rodrigues_v2m(rv, sR);   // the score uses the rotation of the stored vector (PnPRansacCallback::computeError: projectPoints(rvec))
     }
+    __syncthreads();
     HSTAMP(28);
-#undef HSTAMP
-}
-
-// grid = n_hyp, block = 256: float32 squared reprojection error of every point under hypothesis h (PnPRansacCallback::computeError)
-__global__ __launch_bounds__(256) void k_pnp_score(const float* __restrict__ obj, const float* __restrict__ img, int m,
-                                                   const double* __restrict__ K, const double* __restrict__ models,
-                                                   float thr, uint8_t* __restrict__ masks, int* __restrict__ counts) {
-    __shared__ double R[9];
-    __shared__ int wc[4];
-    const int h = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) d_rodrigues_v2m(models + h * 6, R);
-    __syncthreads();
-    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-    const double t0 = models[h * 6 + 3], t1 = models[h * 6 + 4], t2 = models[h * 6 + 5];
-    int good = 0;
-    for (int i = tid; i < m; i += 256) {
-        const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
-        double x = R[0] * X + R[1] * Y + R[2] * Z + t0;
-        double y = R[3] * X + R[4] * Y + R[5] * Z + t1;
-        double z = R[6] * X + R[7] * Y + R[8] * Z + t2;
-        z = z ? 1. / z : 1;
-        x *= z; y *= z;
-        const float px = (float)(x * fx + cx), py = (float)(y * fy + cy);
-        const float dx = img[2 * i] - px, dy = img[2 * i + 1] - py;
-        const float e = dx * dx + dy * dy;
-        const int f = e <= thr;
-        masks[(size_t)h * m + i] = (uint8_t)f;
-        good += f;
-    }
+    // float32 squared reprojection error of every point under this hypothesis, inlier mask and count
+    {
+        const double t0 = sT[0], t1 = sT[1], t2 = sT[2];
+        int good = 0;
+        for (int i = lane; i < m; i += 64) {
+            const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+            double x = sR[0] * X + sR[1] * Y + sR[2] * Z + t0;
+            double y = sR[3] * X + sR[4] * Y + sR[5] * Z + t1;
+            double z = sR[6] * X + sR[7] * Y + sR[8] * Z + t2;
+            z = z ? 1. / z : 1;
+            x *= z; y *= z;
+            const float px = (float)(x * fu + uc), py = (float)(y * fv + vc);
+            const float dx = img[2 * i] - px, dy = img[2 * i + 1] - py;
+            const float e = dx * dx + dy * dy;
+            const int f = e <= thr;
+            masks[(size_t)h * m + i] = (uint8_t)f;
+            good += f;
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) good += __shfl_xor(good, o, 64);
-    if ((tid & 63) == 0) wc[tid >> 6] = good;
-    __syncthreads();
-    if (tid == 0) counts[h] = wc[0] + wc[1] + wc[2] + wc[3];
+        for (int o = 32; o > 0; o >>= 1) good += __shfl_xor(good, o, 64);
+        if (lane == 0) counts[h] = good;
+    }
+    HSTAMP(29);
+#undef HSTAMP
 }
 
 // ---- RANSAC bookkeeping + LM refit (one 256-thread workgroup) -----------------------------------------------------------
@@ -672,9 +666,7 @@ hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
                       double* d_rt_out, int* d_inliers, int* d_info, unsigned long long* d_stamps) {
     { ProfScope ps(K_PNP_HYP, s);
-    hipLaunchKernelGGL(k_pnp_hyp, dim3(n_hyp), dim3(64), 0, s, d_obj, d_img, d_samples, d_K, d_models, d_stamps); }
-    { ProfScope ps(K_PNP_SCORE, s);
-    hipLaunchKernelGGL(k_pnp_score, dim3(n_hyp), dim3(256), 0, s, d_obj, d_img, m, d_K, d_models, thr, d_masks, d_counts); }
+    hipLaunchKernelGGL(k_pnp_hyp, dim3(n_hyp), dim3(64), 0, s, d_obj, d_img, d_samples, d_K, d_models, m, thr, d_masks, d_counts, d_stamps); }
     ProfScope ps3(K_PNP_REFIT, s);
     hipLaunchKernelGGL(k_pnp_select_refit, dim3(1), dim3(RF_T), 0, s, d_obj, d_img, m, d_K, d_models, d_masks, d_counts, n_hyp,
                        confidence, d_rt_out, d_inliers, d_info);

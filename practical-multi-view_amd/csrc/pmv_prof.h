@@ -6,12 +6,12 @@
 
 namespace pmv {
 
-enum KernelId { K_PAD0 = 0, K_PYRDOWN, K_LK, K_GFTT_EIG, K_GFTT_SELECT, K_ST_RESP, K_ST_SELECT, K_PNP_HYP, K_PNP_SCORE, K_PNP_REFIT,
+enum KernelId { K_PAD0 = 0, K_PYRDOWN, K_LK, K_GFTT_EIG, K_GFTT_SELECT, K_ST_RESP, K_ST_SELECT, K_PNP_HYP, K_PNP_REFIT,
                 K_BA_LM, K_BA_RESID, K_TRI_DLT, K_COUNT };
 
 inline const char* kernel_name(int id) {
     static const char* n[K_COUNT] = {"k_pad_level0", "k_pyrdown", "k_lk", "k_gftt_eig", "k_gftt_select", "k_st_resp", "k_st_select",
-                                     "k_pnp_hyp", "k_pnp_score", "k_pnp_select_refit", "k_ba_lm", "k_ba_residuals", "k_tri_dlt"};
+                                     "k_pnp_hyp", "k_pnp_select_refit", "k_ba_lm", "k_ba_residuals", "k_tri_dlt"};
     return (id >= 0 && id < K_COUNT) ? n[id] : "?";
 }
 
