@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
     # bit-parity with the oracle: no FMA contraction, IEEE division/sqrt (hipcc default), no fast-math
-    "-ffp-contract=off", "-fno-fast-math",
+    "-Wall", "-Wuninitialized", "-Winit-self", "-ffp-contract=off", "-fno-fast-math",
     "-Wall", "-Wno-unused-value", "-Wno-unused-result",
 ]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fno-fast-math", "-Wall"]

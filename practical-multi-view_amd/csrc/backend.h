@@ -21,7 +21,8 @@ struct BAArgs {
 hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,
                                const int* pt_idx, int nobs, const double* K, double* out_r, double* out_J);
 hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A);
-// multi-kernel LM (default); d_state: >= 512 B, d_part: >= (nobs/256 + 5*np/64 + 58*nc + 3*nobs + 8) doubles
+// multi-kernel LM (default); d_state: >= 512 + 4*BA_MAX_ITERATIONS B, d_part: >= (nobs/256 + 5*np/64 + 58*nc + 3*nobs + 8) doubles
+constexpr int BA_MAX_ITERATIONS = 512;   // per-iteration flags of the multi-kernel LM
 hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double* d_part);
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,

@@ -55,16 +55,17 @@ int backend_create(pmv_ctx* c) {
     CKB(hipMalloc(&b->d_cobs_start, (nc + 1) * 4)); CKB(hipMalloc(&b->d_cobs_list, no * 4));
     CKB(hipMalloc(&b->d_x, 2 * n * 8)); CKB(hipMalloc(&b->d_cand, n * 8)); CKB(hipMalloc(&b->d_scale, n * 8)); CKB(hipMalloc(&b->d_diag, n * 8));
     CKB(hipMalloc(&b->d_D2, n * 8)); CKB(hipMalloc(&b->d_step, n * 8));
-    CKB(hipMalloc(&b->d_res, no * 2 * 8)); CKB(hipMalloc(&b->d_J, no * 18 * 8));
+    CKB(hipMalloc(&b->d_res, 2 * no * 2 * 8)); CKB(hipMalloc(&b->d_J, 2 * no * 18 * 8));   // two buffers: current point / candidate
     CKB(hipMalloc(&b->d_Einv, np * 9 * 8)); CKB(hipMalloc(&b->d_gp, np * 3 * 8));
     b->ydwd_elems = krows * ldw;
-    CKB(hipMalloc(&b->d_Yd, 2 * b->ydwd_elems * 8));   // Yt | [Wt | g] adjacent: one clear per solve CKB(hipMalloc(&b->d_Wd, b->ydwd_elems * 8));
+    CKB(hipMalloc(&b->d_Yd, 2 * b->ydwd_elems * 8));   // Yt | [Wt | g] adjacent: one clear per solve (multi-kernel LM)
+    CKB(hipMalloc(&b->d_Wd, b->ydwd_elems * 8));       // [Wt | g] of the single-workgroup LM
     CKB(hipMalloc(&b->d_S, m * m * 8)); CKB(hipMalloc(&b->d_rhs, m * 8));
     b->gpart_elems = (size_t)8 * ldw * ldw;   // up to 8 K-slices of an (ldw x ldw) tile grid
     CKB(hipMalloc(&b->d_Gpart, b->gpart_elems * 8));
     CKB(hipMalloc(&b->d_summary, 8 * 8));
     CKB(hipMalloc(&b->d_stamps, 32 * 8));
-    CKB(hipMalloc(&b->d_bastate, 512));
+    CKB(hipMalloc(&b->d_bastate, 512 + 4 * BA_MAX_ITERATIONS));
     CKB(hipMalloc(&b->d_bapart, ((size_t)(no + 255) / 256 + 5 * ((size_t)(np + 63) / 64) + 64 * (size_t)nc + 3 * (size_t)no + 64) * 8));
     CKB(hipMemset(b->d_stamps, 0, 32 * 8));
     const size_t mt = (size_t)c->max_tracks;
@@ -239,7 +240,7 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     REQ(ctx && cams && pts && obs_xy && cam_idx && pt_idx && K, PMV_ERR_INVALID, "pmv_ba_solve: null argument");
     REQ(nc >= 1 && nc <= ctx->max_ba_cams && np >= 1 && np <= ctx->max_ba_points && n_obs >= 1 && n_obs <= ctx->max_ba_obs, PMV_ERR_CAPACITY,
         "pmv_ba_solve: nc=%d np=%d n_obs=%d exceed capacity %d/%d/%d", nc, np, n_obs, ctx->max_ba_cams, ctx->max_ba_points, ctx->max_ba_obs);
-    REQ(max_iterations >= 0 && huber_delta > 0, PMV_ERR_INVALID, "pmv_ba_solve: bad options");
+    REQ(max_iterations >= 1 && max_iterations <= BA_MAX_ITERATIONS && huber_delta > 0, PMV_ERR_INVALID, "pmv_ba_solve: bad options");
     tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     BackendBuffers* b = ctx->be;

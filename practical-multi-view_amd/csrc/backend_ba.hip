@@ -19,7 +19,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int BA_T = 512;
 constexpr int BA_NW = BA_T / 64;
-constexpr int CB_CH = 128;   // camera-block chunk (observations per LDS tile)
+
 
 // ---- ceres::AngleAxisRotatePoint + exact derivatives (both branches) -------------------------------------------------
 __device__ inline void angle_axis_rotate(const double a[3], const double q[3], double p[3], double dpdw[9], double Rm[9], bool jac) {
@@ -789,68 +789,52 @@ __device__ inline void bam_decide(BAGState& s, const double* __restrict__ part4,
         s.decrease = 2.0;
         s.reuse_diag = 0;
         s.need_eval = 1;
-        if (s.iter >= s.max_iterations) { s.x_cost = cc; s.done = 1; s.termination = 0; }
+        s.x_cost = cc;   // the accepted candidate's cost (its r and J were evaluated by the back-substitution kernel)
+        if (s.iter >= s.max_iterations) { s.done = 1; s.termination = 0; }
     } else {
         s.radius /= s.decrease; s.decrease *= 2; s.reuse_diag = 1;
         s.need_eval = 0;
     }
 }
 
-// E: decision on the previous step (it > 0), then r and J (Huber-corrected, Jacobi-scaled once the scaling exists) at the
-// current point; one thread per observation; cost partial per block.
-__device__ inline void bam_eval_role(const BAArgs& A, const BAGState* __restrict__ st_in, BAGState* __restrict__ st_out,
-                                     const double* __restrict__ part4, int nbp, int it, double* __restrict__ part_cost, int bid,
-                                     int nblk) {
-    __shared__ BAGState ss;
+// E0 (first iteration only): initial state, x <- caller's cameras and points, r and J (Huber-corrected, unscaled: the Jacobi
+// scaling is derived from these columns) into buffer 0; one thread per observation; cost partial per block. From the second
+// iteration on the back-substitution kernel evaluates r and J at the candidate, so an accepted step needs no extra pass.
+__device__ inline void bam_eval0_role(const BAArgs& A, BAGState* __restrict__ st_out, int* __restrict__ chol_flags,
+                                      double* __restrict__ part_cost, int bid, int nblk) {
     __shared__ double red[BM_NW];
     const int tid = threadIdx.x;
     const int n = 6 * A.nc + 3 * A.np;
-    if (tid == 0) {
-        if (it == 0) {
+    if (bid == 0) {
+        if (tid == 0) {
+            BAGState ss;
             ss.radius = 1e4; ss.decrease = 2.0; ss.iter = 0; ss.reuse_diag = 0; ss.invalid = 0; ss.need_eval = 1; ss.done = 0;
             ss.termination = 0; ss.successful = 0; ss.chol_fail = 0; ss.first = 1; ss.cur = 0; ss.step_valid = 0;
             ss.gmax = -1.0; ss.x_cost = 0; ss.initial_cost = 0; ss.max_iterations = A.max_iterations; ss.x_norm = 0;
             ss.cand_cost = 0; ss.model_change = 0; ss.step_norm = 0;
-        } else {
-            ss = *st_in;
-            if (!ss.done) bam_decide(ss, part4, nbp);
+            *st_out = ss;
         }
-        if (bid == 0) *st_out = ss;
+        for (int i = tid; i < A.max_iterations; i += BM_T) chol_flags[i] = 0;
     }
-    __syncthreads();
-    if (ss.done || !ss.need_eval) return;
-    const double* xc; const double* xp;
-    if (it == 0) {   // the parameter vector starts as the caller's cameras and points
-        xc = A.cams; xp = A.pts;
-        for (int i = bid * BM_T + tid; i < n; i += nblk * BM_T) A.x[i] = (i < 6 * A.nc) ? A.cams[i] : A.pts[i - 6 * A.nc];
-    } else { xc = A.x + (size_t)ss.cur * n; xp = xc + 6 * A.nc; }
+    for (int i = bid * BM_T + tid; i < n; i += nblk * BM_T) A.x[i] = (i < 6 * A.nc) ? A.cams[i] : A.pts[i - 6 * A.nc];
     const int i = bid * BM_T + tid;
     double cpart = 0;
     if (i < A.nobs) {
         const int c = A.cam_idx[i], p = A.pt_idx[i];
         CamRot cr;
-        cam_rot_setup(xc + 6 * c, cr);
+        cam_rot_setup(A.cams + 6 * c, cr);
         double r[2], Jc[12], Jp[6];
-        projection_residual_pre(cr, xc + 6 * c, xp + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, Jc, Jp, true);
+        projection_residual_pre(cr, A.cams + 6 * c, A.pts + 3 * p, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, Jc, Jp, true);
         double rho0, rho1;
         huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
         cpart = 0.5 * rho0;
         const double sr = sqrt(rho1);
         A.res[2 * i] = r[0] * sr; A.res[2 * i + 1] = r[1] * sr;
         double* Jo = A.J + (size_t)i * 18;
-        if (ss.first) {
 #pragma unroll
-            for (int k = 0; k < 12; k++) Jo[k] = Jc[k] * sr;
+        for (int k = 0; k < 12; k++) Jo[k] = Jc[k] * sr;
 #pragma unroll
-            for (int k = 0; k < 6; k++) Jo[12 + k] = Jp[k] * sr;
-        } else {
-            const double* sc = A.scale + 6 * c;
-            const double* sp = A.scale + 6 * A.nc + 3 * p;
-#pragma unroll
-            for (int k = 0; k < 12; k++) Jo[k] = Jc[k] * sr * sc[k % 6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) Jo[12 + k] = Jp[k] * sr * sp[k % 3];
-        }
+        for (int k = 0; k < 6; k++) Jo[12 + k] = Jp[k] * sr;
     }
     cpart = wave_sum_f64(cpart);
     if ((tid & 63) == 0) red[tid >> 6] = cpart;
@@ -858,21 +842,22 @@ __device__ inline void bam_eval_role(const BAArgs& A, const BAGState* __restrict
     if (tid == 0) part_cost[bid] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(BM_T) void k_bam_eval(BAArgs A, const BAGState* st_in, BAGState* st_out, const double* part4, int nbp, int it,
-                                                   double* part_cost) {
-    bam_eval_role(A, st_in, st_out, part4, nbp, it, part_cost, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(BM_T) void k_bam_eval0(BAArgs A, BAGState* st_out, int* chol_flags, double* part_cost) {
+    bam_eval0_role(A, st_out, chol_flags, part_cost, blockIdx.x, gridDim.x);
 }
 
 // C role: one block (4 wavefronts) per camera: U_c (6x6) and rhs_c on FP64 MFMA; in the first iteration also the Jacobi
 // scale of the camera's parameters (from the unscaled column norms = diag U_c) and the rescaled block.
-__device__ inline void bam_cam_role(const BAArgs& A, const BAGState* __restrict__ st, int c, double* __restrict__ Ublk,
+__device__ inline void bam_cam_role(const BAArgs& A, const BAGState& st, int c, double* __restrict__ Ublk,
                                     double* __restrict__ rhsblk, double* sred /* [BM_NW][64][4] */, double* ssc /* 8 */) {
-    if (st->done || !st->need_eval) return;
+    if (st.done || !st.need_eval) return;
+    const double* Jb = A.J + (size_t)st.cur * A.nobs * 18;
+    const double* resb = A.res + (size_t)st.cur * A.nobs * 2;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int e0 = A.cobs_start[c], e1 = A.cobs_start[c + 1];
     const int per = (((e1 - e0) + BM_NW - 1) / BM_NW + 7) & ~7;   // observations per wavefront, whole MFMA batches (8 obs)
     const int w0 = min(e1, e0 + wid * per), w1 = min(e1, w0 + per);
-    const v4d d = cam_block_mfma(A.J, A.res, A.cobs_list, w0, w1, lane);
+    const v4d d = cam_block_mfma(Jb, resb, A.cobs_list, w0, w1, lane);
 #pragma unroll
     for (int r = 0; r < 4; r++) sred[(wid * 4 + r) * 64 + lane] = d[r];
     __syncthreads();
@@ -881,7 +866,7 @@ __device__ inline void bam_cam_role(const BAArgs& A, const BAGState* __restrict_
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = (sred[(0 * 4 + r) * 64 + lane] + sred[(1 * 4 + r) * 64 + lane]) + (sred[(2 * 4 + r) * 64 + lane] + sred[(3 * 4 + r) * 64 + lane]);
     const int col = lane & 15;
-    const bool first = st->first != 0;
+    const bool first = st.first != 0;
     if (first) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -907,9 +892,11 @@ __device__ inline void bam_cam_role(const BAArgs& A, const BAGState* __restrict_
 // observation of the block's points: the observation's 6x3 blocks of Wt and Yt = W E^-1. Gradient-max partial per block.
 constexpr int BM_OB = 8;    // observations of a point handled per register batch
 constexpr int BM_PB = 64;   // points per block
-__device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st, int pb, double* __restrict__ part_gmax,
-                                      double* sEi /* [BM_PB][9] */, double* red) {
-    if (st->done) return;
+__device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* __restrict__ chol_flag, int pb,
+                                      double* __restrict__ part_gmax, double* sEi /* [BM_PB][9] */) {
+    if (st.done) return;
+    double* Jb = A.J + (size_t)st.cur * A.nobs * 18;
+    const double* resb = A.res + (size_t)st.cur * A.nobs * 2;
     const int m = 6 * A.nc, krows = A.krows;
     const int tid = threadIdx.x;
     const int p0 = pb * BM_PB, p1 = min(A.np, p0 + BM_PB);
@@ -917,10 +904,10 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
     double gmax_p = 0;
     if (tid < BM_PB && p < p1) {
         const int e0 = A.pobs_start[p], e1 = A.pobs_start[p + 1];
-        if (st->first) {   // Jacobi scaling: columns of the point from its own rows, columns of the cameras from the C kernel
+        if (st.first) {   // Jacobi scaling: columns of the point from its own rows, columns of the cameras from the C kernel
             double acc[3] = {0, 0, 0};
             for (int e = e0; e < e1; e++) {
-                const double* Jp = A.J + (size_t)A.pobs_list[e] * 18 + 12;
+                const double* Jp = Jb + (size_t)A.pobs_list[e] * 18 + 12;
 #pragma unroll
                 for (int k = 0; k < 3; k++) acc[k] += Jp[k] * Jp[k] + Jp[3 + k] * Jp[3 + k];
             }
@@ -930,7 +917,7 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
             for (int e = e0; e < e1; e++) {
                 const int i = A.pobs_list[e];
                 const double* sc = A.scale + 6 * A.cam_idx[i];
-                double* Jo = A.J + (size_t)i * 18;
+                double* Jo = Jb + (size_t)i * 18;
 #pragma unroll
                 for (int k = 0; k < 12; k++) Jo[k] *= sc[k % 6];
 #pragma unroll
@@ -946,10 +933,10 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
 #pragma unroll
             for (int u = 0; u < BM_OB; u++) {
                 if (oi[u] >= 0) {
-                    const double* Jp = A.J + (size_t)oi[u] * 18 + 12;
+                    const double* Jp = Jb + (size_t)oi[u] * 18 + 12;
 #pragma unroll
                     for (int k = 0; k < 6; k++) jp[u][k] = Jp[k];
-                    rr[u][0] = A.res[2 * oi[u]]; rr[u][1] = A.res[2 * oi[u] + 1];
+                    rr[u][0] = resb[2 * oi[u]]; rr[u][1] = resb[2 * oi[u] + 1];
                 } else {
 #pragma unroll
                     for (int k = 0; k < 6; k++) jp[u][k] = 0;
@@ -968,8 +955,8 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
                 }
             }
         }
-        const double radius = st->radius;
-        const bool reuse = st->reuse_diag != 0;
+        const double radius = st.radius;
+        const bool reuse = st.reuse_diag != 0;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             double dg;
@@ -991,7 +978,7 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
             ok = ok && (d > 0.0); L[8] = sqrt(d);
         }
         double Ei[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (!ok) atomicOr(&st->chol_fail, 1);   // the step is invalid: the solve kernel stops, nothing below is used
+        if (!ok) atomicOr(chol_flag, 1);   // the step is invalid: the solve kernel stops, nothing below is used
         else {
 #pragma unroll
             for (int cI = 0; cI < 3; cI++) {
@@ -1021,7 +1008,7 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
         if (flag == 2) continue;   // a later observation of the same (point, camera): folded into the first one
         const int i = A.pobs_list[e];
         const int c = A.cam_idx[i], pp = A.pt_idx[i];
-        const double* Jr = A.J + (size_t)i * 18;
+        const double* Jr = Jb + (size_t)i * 18;
         double jc[12], jp[6];
 #pragma unroll
         for (int k = 0; k < 12; k++) jc[k] = Jr[k];
@@ -1037,7 +1024,7 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
             for (int e2 = e + 1; e2 < A.pobs_start[pp + 1]; e2++) {
                 const int i2 = A.pobs_list[e2];
                 if (A.cam_idx[i2] != c) continue;
-                const double* J2 = A.J + (size_t)i2 * 18;
+                const double* J2 = Jb + (size_t)i2 * 18;
 #pragma unroll
                 for (int a = 0; a < 6; a++) {
 #pragma unroll
@@ -1060,22 +1047,35 @@ __device__ inline void bam_point_role(const BAArgs& A, BAGState* __restrict__ st
             }
         }
     }
-    (void)red;
 }
 
 // blocks [0, cam_blocks): C role; blocks [cam_blocks, cam_blocks + point_blocks): P role
 constexpr int BM_WORK = BM_NW * 4 * 64;   // doubles of block-shared scratch: MFMA accumulators per wavefront / E^-1 of a block's points
-__device__ inline void bam_campoint_role(const BAArgs& A, BAGState* st, int cam_blocks, double* Ublk, double* rhsblk, double* part_gmax,
-                                         int bid, double* sred /* [BM_WORK] */) {
+// C|P kernel. From the second iteration on every block first takes the accept/reject decision on the previous step itself
+// (same inputs, same arithmetic in every block; block 0 publishes the new state) — the state is double-buffered so nobody
+// reads what block 0 writes. Blocks [0, cam_blocks): C role; the rest: P role.
+__device__ inline void bam_campoint_role(const BAArgs& A, const BAGState* __restrict__ st_in, BAGState* __restrict__ st_out, bool decide,
+                                         const double* __restrict__ part4, int nbp, int* __restrict__ chol_flag, int cam_blocks,
+                                         double* Ublk, double* rhsblk, double* part_gmax, int bid, double* sred /* [BM_WORK] */) {
+    __shared__ BAGState ss;
     __shared__ double ssc[8];
     static_assert(BM_PB * 9 <= BM_WORK, "LDS");
-    if (bid < cam_blocks) bam_cam_role(A, st, bid, Ublk, rhsblk, sred, ssc);
-    else bam_point_role(A, st, bid - cam_blocks, part_gmax, sred, ssc);
+    if (threadIdx.x == 0) {
+        ss = *st_in;
+        if (decide) {
+            if (!ss.done) bam_decide(ss, part4, nbp);
+            if (bid == 0) *st_out = ss;
+        }
+    }
+    __syncthreads();
+    if (bid < cam_blocks) bam_cam_role(A, ss, bid, Ublk, rhsblk, sred, ssc);
+    else bam_point_role(A, ss, chol_flag, bid - cam_blocks, part_gmax, sred);
 }
-__global__ __launch_bounds__(BM_T) void k_bam_campoint(BAArgs A, BAGState* st, int cam_blocks, double* Ublk, double* rhsblk,
+__global__ __launch_bounds__(BM_T) void k_bam_campoint(BAArgs A, const BAGState* st_in, BAGState* st_out, int decide, const double* part4,
+                                                       int nbp, int* chol_flag, int cam_blocks, double* Ublk, double* rhsblk,
                                                        double* part_gmax) {
     __shared__ double swork[BM_WORK];
-    bam_campoint_role(A, st, cam_blocks, Ublk, rhsblk, part_gmax, blockIdx.x, swork);
+    bam_campoint_role(A, st_in, st_out, decide != 0, part4, nbp, chol_flag, cam_blocks, Ublk, rhsblk, part_gmax, blockIdx.x, swork);
 }
 
 // G: Schur contraction  G = Yt^T [Wt | g]  on FP64 MFMA: BG_H blocks per 16x16 tile, one wavefront per K-slice, the slices
@@ -1134,8 +1134,8 @@ __global__ __launch_bounds__(64 * BG_W) void k_bam_gemm(BAArgs A, const BAGState
 // S: loop-top tests, reduced camera system [S | rhs row] in LDS, right-looking Cholesky with the forward substitution
 // folded in as row m (two barriers per column), backward substitution in registers of wavefront 0 -> step_c; rotation
 // constants of the candidate cameras.
-__device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const double* __restrict__ part_cost, int nbo,
-                                      const double* __restrict__ part_gmax, int nbp, const double* __restrict__ Ublk,
+__device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const int* __restrict__ chol_flag, const double* __restrict__ part_cost,
+                                      int nbo, const double* __restrict__ part_gmax, int nbp, const double* __restrict__ Ublk,
                                       const double* __restrict__ rhsblk, double* __restrict__ candrot) {
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ double red[3 * BM_NW];
@@ -1163,10 +1163,12 @@ __device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const doubl
         if (lane == 0) { red[wid] = xn; red[BM_NW + wid] = cs; red[2 * BM_NW + wid] = g; }
         __syncthreads();
         if (tid == 0) {
-            const double c = (red[BM_NW] + red[BM_NW + 1]) + (red[BM_NW + 2] + red[BM_NW + 3]);
-            ss.x_cost = st->x_cost = c;
+            if (ss.first) {   // cost of the starting point (E0); later x_cost is the accepted candidate's cost
+                const double c = (red[BM_NW] + red[BM_NW + 1]) + (red[BM_NW + 2] + red[BM_NW + 3]);
+                ss.x_cost = st->x_cost = c;
+                ss.initial_cost = st->initial_cost = c;
+            }
             ss.x_norm = st->x_norm = sqrt((red[0] + red[1]) + (red[2] + red[3]));
-            if (ss.iter == 0) ss.initial_cost = st->initial_cost = c;
             ss.gmax = st->gmax = fmax(fmax(red[2 * BM_NW], red[2 * BM_NW + 1]), fmax(red[2 * BM_NW + 2], red[2 * BM_NW + 3]));
         }
     }
@@ -1206,7 +1208,7 @@ __device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const doubl
         }
     }
     __syncthreads();
-    if (ss.chol_fail) return;   // a point block was not positive definite: invalid step (step_valid stays 0)
+    if (*chol_flag) return;   // a point block was not positive definite: invalid step (step_valid stays 0)
     SSTAMP(17);
     // Blocked right-looking Cholesky, block = one camera (6 columns). Per block: (a) one thread factors the 6x6 diagonal
     // block in registers (the only serial chain: 6 x sqrt + reciprocal), (b) one thread per row below solves its 6 entries
@@ -1349,9 +1351,10 @@ __device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const doubl
 #undef SSTAMP
 }
 
-__global__ __launch_bounds__(BM_T) void k_bam_solve(BAArgs A, BAGState* st, const double* part_cost, int nbo, const double* part_gmax,
-                                                    int nbp, const double* Ublk, const double* rhsblk, double* candrot) {
-    bam_solve_role(A, st, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot);
+__global__ __launch_bounds__(BM_T) void k_bam_solve(BAArgs A, BAGState* st, const int* chol_flag, const double* part_cost, int nbo,
+                                                    const double* part_gmax, int nbp, const double* Ublk, const double* rhsblk,
+                                                    double* candrot) {
+    bam_solve_role(A, st, chol_flag, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot);
 }
 
 // B: one block per BM_PB points. Phase A, per observation: Jp^T (Jc y_c); phase B, per point: back-substitution and the
@@ -1363,15 +1366,21 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
     if (st->done || !st->step_valid) return;
     const int tid = threadIdx.x;
     const int nc = A.nc, m = 6 * nc, n = m + 3 * A.np;
-    const double* x = A.x + (size_t)st->cur * n;
-    double* cand = A.x + (size_t)(st->cur ^ 1) * n;
+    const int cur = st->cur;
+    const double* x = A.x + (size_t)cur * n;
+    double* cand = A.x + (size_t)(cur ^ 1) * n;
+    const double* Jb = A.J + (size_t)cur * A.nobs * 18;          // r, J at the current point
+    const double* resb = A.res + (size_t)cur * A.nobs * 2;
+    double* Jn = A.J + (size_t)(cur ^ 1) * A.nobs * 18;          // r, J at the candidate (used if the step is accepted)
+    double* resn = A.res + (size_t)(cur ^ 1) * A.nobs * 2;
+    const bool spec = st->iter + 1 < st->max_iterations;         // after the last iteration nobody reads them
     const int p0 = bid * BM_PB, p1 = min(A.np, p0 + BM_PB);
     const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
     double mc = 0, cc = 0, dn2 = 0;
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
         const int i = A.pobs_list[e];
         const int c = A.cam_idx[i];
-        const double* Jr = A.J + (size_t)i * 18;
+        const double* Jr = Jb + (size_t)i * 18;
         double jy0 = 0, jy1 = 0;   // y_c = -step_c
 #pragma unroll
         for (int a = 0; a < 6; a++) { const double yc = -A.step[6 * c + a]; jy0 += Jr[a] * yc; jy1 += Jr[6 + a] * yc; }
@@ -1402,7 +1411,7 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
         const int i = A.pobs_list[e];
         const int c = A.cam_idx[i], pl = A.pt_idx[i] - p0;
-        const double* Jr = A.J + (size_t)i * 18;
+        const double* Jr = Jb + (size_t)i * 18;
         double sc[6], sp[3], xp[3];
 #pragma unroll
         for (int k = 0; k < 6; k++) sc[k] = A.step[6 * c + k];
@@ -1415,15 +1424,29 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
             for (int k = 0; k < 6; k++) mr += Jr[rr * 6 + k] * sc[k];
 #pragma unroll
             for (int k = 0; k < 3; k++) mr += Jr[12 + rr * 3 + k] * sp[k];
-            mc -= mr * (A.res[2 * i + rr] + mr / 2.0);
+            mc -= mr * (resb[2 * i + rr] + mr / 2.0);
         }
         const double* o = candrot + 16 * c;
         CamRot cr;
         cr.ct = o[6]; cr.st = o[7]; cr.ti = o[8]; cr.w0 = o[9]; cr.w1 = o[10]; cr.w2 = o[11]; cr.big = (int)o[12];
-        double r[2];
-        projection_residual_pre(cr, o, xp, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, nullptr, nullptr, false);
-        double rho0, rho1;
-        huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
+        double r[2], rho0, rho1;
+        if (spec) {
+            double Jc[12], Jp[6];
+            projection_residual_pre(cr, o, xp, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, Jc, Jp, true);
+            huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
+            const double sr = sqrt(rho1);
+            resn[2 * i] = r[0] * sr; resn[2 * i + 1] = r[1] * sr;
+            const double* scc = A.scale + 6 * c;
+            const double* scp = A.scale + 6 * A.nc + 3 * (pl + p0);
+            double* Jo = Jn + (size_t)i * 18;
+#pragma unroll
+            for (int k = 0; k < 12; k++) Jo[k] = Jc[k] * sr * scc[k % 6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Jo[12 + k] = Jp[k] * sr * scp[k % 3];
+        } else {
+            projection_residual_pre(cr, o, xp, A.obs[2 * i], A.obs[2 * i + 1], A.K, r, nullptr, nullptr, false);
+            huber_rho(r[0] * r[0] + r[1] * r[1], A.huber, rho0, rho1);
+        }
         cc += 0.5 * rho0;
     }
     if (bid == 0) {   // camera part of the candidate and of the step norm
@@ -1471,6 +1494,7 @@ __global__ __launch_bounds__(BM_T) void k_bam_finish(BAArgs A, const BAGState* s
 
 hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double* d_part) {
     BAGState* st2[2] = {(BAGState*)d_state, (BAGState*)((char*)d_state + 256)};   // double-buffered state
+    int* chol_flags = (int*)((char*)d_state + 512);                                // one "point block not SPD" flag per iteration
     static_assert(sizeof(BAGState) <= 256, "BAGState");
     const int nbo = (A.nobs + BM_T - 1) / BM_T, nbp = (A.np + BM_PB - 1) / BM_PB, m = 6 * A.nc;
     double* part_cost = d_part;                 // nbo
@@ -1481,6 +1505,7 @@ hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double
     double* candrot = rhsblk + 6 * A.nc;        // nc * 16
     double* tmp3 = candrot + 16 * A.nc;         // nobs * 3
     const size_t shm = ((size_t)(m + 1) * m + (size_t)m) * sizeof(double);
+    if (A.max_iterations > BA_MAX_ITERATIONS) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_bam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -1492,17 +1517,19 @@ hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double
     if (e != hipSuccess) return e;
     ProfScope ps(K_BA_LM, s);
     const int tiles = A.tiles_r * A.tiles_c;
+    // launches: E0, then per iteration C|P (with the decision on the previous step) -> G -> S -> B, then F
+    hipLaunchKernelGGL(k_bam_eval0, dim3(nbo), dim3(BM_T), 0, s, A, st2[1], chol_flags, part_cost);
     for (int it = 0; it < A.max_iterations; it++) {
         BAGState* sin = st2[it & 1];
         BAGState* sc = st2[(it + 1) & 1];   // the state of this iteration
-        hipLaunchKernelGGL(k_bam_eval, dim3(nbo), dim3(BM_T), 0, s, A, sin, sc, part4, nbp, it, part_cost);
+        int* cf = chol_flags + it;
         if (it == 0) {   // the point kernel needs the camera scales of the C kernel in the first iteration
-            hipLaunchKernelGGL(k_bam_campoint, dim3(A.nc), dim3(BM_T), 0, s, A, sc, A.nc, Ublk, rhsblk, part_gmax);
-            hipLaunchKernelGGL(k_bam_campoint, dim3(nbp), dim3(BM_T), 0, s, A, sc, 0, Ublk, rhsblk, part_gmax);
+            hipLaunchKernelGGL(k_bam_campoint, dim3(A.nc), dim3(BM_T), 0, s, A, sc, sc, 0, part4, nbp, cf, A.nc, Ublk, rhsblk, part_gmax);
+            hipLaunchKernelGGL(k_bam_campoint, dim3(nbp), dim3(BM_T), 0, s, A, sc, sc, 0, part4, nbp, cf, 0, Ublk, rhsblk, part_gmax);
         } else
-            hipLaunchKernelGGL(k_bam_campoint, dim3(A.nc + nbp), dim3(BM_T), 0, s, A, sc, A.nc, Ublk, rhsblk, part_gmax);
+            hipLaunchKernelGGL(k_bam_campoint, dim3(A.nc + nbp), dim3(BM_T), 0, s, A, sin, sc, 1, part4, nbp, cf, A.nc, Ublk, rhsblk, part_gmax);
         hipLaunchKernelGGL(k_bam_gemm, dim3(tiles * BG_H), dim3(64 * BG_W), 0, s, A, sc);
-        hipLaunchKernelGGL(k_bam_solve, dim3(1), dim3(BM_T), shm, s, A, sc, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot);
+        hipLaunchKernelGGL(k_bam_solve, dim3(1), dim3(BM_T), shm, s, A, sc, cf, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot);
         hipLaunchKernelGGL(k_bam_backsub, dim3(nbp), dim3(BM_T), 0, s, A, sc, candrot, tmp3, part4);
     }
     hipLaunchKernelGGL(k_bam_finish, dim3(1), dim3(BM_T), 0, s, A, st2[A.max_iterations & 1], part4, nbp);
