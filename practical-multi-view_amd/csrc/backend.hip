@@ -40,6 +40,7 @@ struct BackendBuffers {
     uint8_t* d_masks = nullptr;
 };
 
+constexpr size_t PNP_HDR = 384;   // bytes: K (10 doubles) + 33 powers of ten + padding
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 int backend_create(pmv_ctx* c) {
@@ -78,7 +79,7 @@ int backend_create(pmv_ctx* c) {
     CKB(hipMalloc(&b->d_masks, (size_t)MAX_HYP * mt));
     b->ba_io_bytes = (8 + nc * 6 + np * 3 + no * 2 + 10) * 8 + (no * 5 + np + nc + 8) * 4 + 64;
     CKB(hipMalloc(&b->d_ba_io, b->ba_io_bytes));
-    b->pnp_in_bytes = 80 + mt * 20 + (size_t)MAX_HYP * 20 + 64;
+    b->pnp_in_bytes = PNP_HDR + mt * 20 + (size_t)MAX_HYP * 20 + 64;
     b->pnp_out_bytes = 48 + 16 + mt * 4 + 64;
     CKB(hipMalloc(&b->d_pnp_in, b->pnp_in_bytes));
     CKB(hipMalloc(&b->d_pnp_out, b->pnp_out_bytes));
@@ -145,13 +146,14 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     BackendBuffers* b = ctx->be;
     hipStream_t s = ctx->s_back;
     char* hs = (char*)b->h_stage;
-    // one pinned block: [K 10 doubles | obj 3m floats | img 2m floats | samples 5*iterations ints]
+    // one pinned block: [K 10 doubles, 10^k for k = -16..16 (CvLevMarq's lambda) | obj 3m floats | img 2m floats | samples 5*iterations ints]
     double* h_K = (double*)hs;
-    float* h_obj = (float*)(hs + 80);
+    float* h_obj = (float*)(hs + PNP_HDR);
     float* h_img = h_obj + (size_t)3 * m;
     int* h_samples = (int*)(h_img + (size_t)2 * m);
-    const size_t in_bytes = 80 + (size_t)m * 20 + (size_t)iterations * 20;
+    const size_t in_bytes = PNP_HDR + (size_t)m * 20 + (size_t)iterations * 20;
     memcpy(h_K, K, 72);
+    for (int k = -16; k <= 16; k++) h_K[10 + 16 + k] = std::exp(k * std::log(10.));   // as CvLevMarq::step evaluates it (host libm)
     memcpy(h_obj, obj_xyz, (size_t)m * 12);
     memcpy(h_img, img_xy, (size_t)m * 8);
     CvRNG rng((uint64_t)-1);
@@ -170,7 +172,7 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     }
     CKC(hipMemcpyAsync(b->d_pnp_in, hs, in_bytes, hipMemcpyHostToDevice, s));
     const double* d_K = (const double*)b->d_pnp_in;
-    const float* d_obj = (const float*)(b->d_pnp_in + 80);
+    const float* d_obj = (const float*)(b->d_pnp_in + PNP_HDR);
     const float* d_img = d_obj + (size_t)3 * m;
     const int* d_samples = (const int*)(d_img + (size_t)2 * m);
     double* d_rt = (double*)b->d_pnp_out;

@@ -12,9 +12,11 @@
 
 namespace pmv {
 
+#define WAVE_SYNC_PNP() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 // ---- EPnP on 5 points; per-hypothesis state lives in LDS (one wavefront = one hypothesis) ---------------------------------
 struct EpnpShared {
-    double A[144], B[144], V[144];
+    double A[144], V[144];
     double M[10 * 12];
     double C[6], S[6];
     int P[6], Q[6];
@@ -22,7 +24,6 @@ struct EpnpShared {
     double v4[48];
     double L[60], rho[6];
     double case_err[3], case_R[27], case_t[9];
-    int rotated;
 };
 
 __device__ void epnp_qr_solve(double* A, double* b, double* X) {   // epnp::qr_solve, 6x4
@@ -234,14 +235,18 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
         sh.V[idx] = (a == b) ? 1.0 : 0.0;
     }
     __syncthreads();
-    // parallel-order (round-robin) Jacobi: 6 disjoint rotations per round
+    // parallel-order (round-robin) Jacobi: 6 disjoint rotations per round. The block is one wavefront, so LDS ordering
+    // (s_waitcnt) is all the synchronisation needed. A <- J^T A J is applied in one pass: the item (g, g') owns the 2x2
+    // block {p,q} x {p',q'} (pairs partition the indices, so items touch disjoint elements and update in place), computing
+    // first the column rotation of pair g' and then the row rotation of pair g — the same expressions, in the same order,
+    // as B = A J followed by A = J^T B. A round in which no pair rotates is skipped (it would multiply by the identity).
     double tol_abs = 0;
     for (int i = 0; i < 12; i++) tol_abs += fabs(sh.A[i * 13]);
     tol_abs *= 1e-17;
     for (int sweep = 0; sweep < 30; sweep++) {
-        if (lane == 0) sh.rotated = 0;
-        __syncthreads();
+        int rotated = 0;
         for (int r = 0; r < 11; r++) {
+            bool rot = false;
             if (lane < 6) {
                 const int g = lane;
                 int a, b;
@@ -257,34 +262,36 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
                     const double c = 1.0 / sqrt(t * t + 1.0);
                     sh.C[g] = c;
                     sh.S[g] = t * c;
-                    atomicAdd(&sh.rotated, 1);
+                    rot = true;
                 }
             }
-            __syncthreads();
-            for (int idx = lane; idx < 72; idx += 64) {   // B = A J and V = V J, item = (row i, pair g)
+            const int nrot = __popcll(__ballot(rot));
+            rotated += nrot;
+            WAVE_SYNC_PNP();
+            if (nrot == 0) continue;   // wave-uniform
+            if (lane < 36) {
+                const int g = lane / 6, g2 = lane - g * 6;
+                const int p = sh.P[g], q = sh.Q[g], p2 = sh.P[g2], q2 = sh.Q[g2];
+                const double c = sh.C[g], sn = sh.S[g], c2 = sh.C[g2], sn2 = sh.S[g2];
+                const double app = sh.A[p * 12 + p2], apq = sh.A[p * 12 + q2], aqp = sh.A[q * 12 + p2], aqq = sh.A[q * 12 + q2];
+                const double bpp = c2 * app - sn2 * apq, bpq = sn2 * app + c2 * apq;   // B = A J, rows p and q
+                const double bqp = c2 * aqp - sn2 * aqq, bqq = sn2 * aqp + c2 * aqq;
+                sh.A[p * 12 + p2] = c * bpp - sn * bqp;                                 // A = J^T B
+                sh.A[q * 12 + p2] = sn * bpp + c * bqp;
+                sh.A[p * 12 + q2] = c * bpq - sn * bqq;
+                sh.A[q * 12 + q2] = sn * bpq + c * bqq;
+            }
+            for (int idx = lane; idx < 72; idx += 64) {   // V = V J, item = (row i, pair g)
                 const int i = idx / 6, g = idx - i * 6;
                 const int p = sh.P[g], q = sh.Q[g];
-                const double c = sh.C[g], s = sh.S[g];
-                double x = sh.A[i * 12 + p], y = sh.A[i * 12 + q];
-                sh.B[i * 12 + p] = c * x - s * y;
-                sh.B[i * 12 + q] = s * x + c * y;
-                x = sh.V[i * 12 + p]; y = sh.V[i * 12 + q];
-                sh.V[i * 12 + p] = c * x - s * y;
-                sh.V[i * 12 + q] = s * x + c * y;
+                const double c = sh.C[g], sn = sh.S[g];
+                const double x = sh.V[i * 12 + p], y = sh.V[i * 12 + q];
+                sh.V[i * 12 + p] = c * x - sn * y;
+                sh.V[i * 12 + q] = sn * x + c * y;
             }
-            __syncthreads();
-            for (int idx = lane; idx < 72; idx += 64) {   // A = J^T B, item = (column j, pair g)
-                const int j = idx / 6, g = idx - j * 6;
-                const int p = sh.P[g], q = sh.Q[g];
-                const double c = sh.C[g], s = sh.S[g];
-                const double x = sh.B[p * 12 + j], y = sh.B[q * 12 + j];
-                sh.A[p * 12 + j] = c * x - s * y;
-                sh.A[q * 12 + j] = s * x + c * y;
-            }
-            __syncthreads();
+            WAVE_SYNC_PNP();
         }
-        if (!sh.rotated) break;
-        __syncthreads();
+        if (!rotated) break;
     }
     HSTAMP(23);
     if (lane == 0) {
@@ -478,10 +485,10 @@ __device__ inline void block_sum28(const double* acc, RefitShared& sh) {
     if (tid < 28 * 8) {
         const int k = tid >> 3, part = tid & 7;
         const double* src = &sh.tile[k * RF_T + part * 32];
-        double sacc = 0;
-#pragma unroll 8
-        for (int j = 0; j < 32; j++) sacc += src[j];
-        sh.part[k * 8 + part] = sacc;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // four independent chains (fixed order), 8 dependent adds instead of 32
+#pragma unroll
+        for (int j = 0; j < 32; j += 4) { s0 += src[j]; s1 += src[j + 1]; s2 += src[j + 2]; s3 += src[j + 3]; }
+        sh.part[k * 8 + part] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     if (tid < 28) {
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
             }
             sh.state = do_step ? (sh.state | 2) : sh.state;   // bit 1: a step has to be solved by wave 0 below
             if (do_step) {
-                const double lambda = exp(sh.lambdaLg10 * log(10.));
+                const double lambda = K[10 + 16 + sh.lambdaLg10];   // exp(lambdaLg10 * log(10.)) tabulated by the host (|lambdaLg10| <= 16)
                 for (int i = 0; i < 6; i++) {
                     for (int k = 0; k < 6; k++) sh.Aug[i * 7 + k] = sh.JtJ[i * 6 + k];
                     sh.Aug[i * 7 + i] *= 1. + lambda;

@@ -4,6 +4,8 @@
 #pragma once
 #include "vo_pipeline.h"
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace vo {
 
@@ -60,6 +62,11 @@ inline void pipeline_execute(PipelineRun& run, const PipelineParams& P) {
     if (P.threaded) run.pipe.run_threaded();
     else run.pipe.run();
     run.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("PMV_HOST_PROF")) {
+        fprintf(stderr, "[host-prof] run %.4f s:", run.seconds);
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.4f", HostProf::name(i), run.pipe.stats.hp.t[i]);
+        fprintf(stderr, "\n");
+    }
 }
 
 // poses: for i in [0, n_poses): 12 doubles = R (row-major 9) then t (3)

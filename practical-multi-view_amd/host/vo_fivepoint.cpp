@@ -429,6 +429,7 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     const int j = src.frame;
     std::vector<double> p1, p2;
     std::vector<std::shared_ptr<Feature>> p1_ptr, p2_ptr;
+    HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[4]);
     for (auto& p : src.feat_corr) {
         if (p.first.expired() || p.second.expired()) continue;
         std::shared_ptr<Feature> fst = p.first.lock();
@@ -438,6 +439,7 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
         p1_ptr.push_back(fst);
         p2_ptr.push_back(sec);
     }
+    delete hpg;
     const int n = (int)p1_ptr.size();
     std::vector<uint8_t> mask;
     std::vector<double> tri;
@@ -461,6 +463,7 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     const double d0 = g1.v[0] - g0.v[0], d1 = g1.v[1] - g0.v[1], d2 = g1.v[2] - g0.v[2];
     tracker->scale = std::sqrt(std::pow(d0, 2) + std::pow(d1, 2) + std::pow(d2, 2));
     t_out = tracker->scale * t_out;
+    HostProfScope hpl(tracker->stats.hp.t[5]);
     for (int i = 0; i < n; i++) {
         if (!mask[i]) continue;   // Removing RANSAC outliers
         const double w = tri[(size_t)3 * n + i];

@@ -108,11 +108,13 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
     double _R_rod[3];
     rodrigues_m2v(R_out.m, _R_rod);
     std::vector<std::weak_ptr<Feature3D>> local_feats3d;
+    HostProfScope* hps = new HostProfScope(tracker->stats.hp.t[0]);
+    obj_points.reserve(3 * src.map.size()); img_points.reserve(2 * src.map.size()); local_feats3d.reserve(src.map.size());
     for (auto& p : src.map) {
-        if (p.second.expired()) continue;
-        std::shared_ptr<Feature3D> f3d = p.second.lock();
-        if (src.feat_corr[p.first].expired()) continue;      // operator[] inserts empty entries (quirk Q10)
-        std::shared_ptr<Feature> f = src.feat_corr[p.first].lock();
+        std::shared_ptr<Feature3D> f3d = p.second.lock();    // (expired() + lock() in the reference: one atomic round trip here)
+        if (!f3d) continue;
+        std::shared_ptr<Feature> f = src.feat_corr[p.first].lock();   // operator[] inserts empty entries (quirk Q10); looked up once
+        if (!f) continue;
         next.map[f] = std::weak_ptr<Feature3D>(f3d);
         f3d->transformInv(tracker->R[j], tracker->t[j]);
         float px = f3d->x, py = f3d->y, pz = f3d->z;
@@ -120,8 +122,9 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
         obj_points.push_back(px); obj_points.push_back(py); obj_points.push_back(pz);
         img_points.push_back((float)f->column); img_points.push_back((float)f->row);
         f3d->transform(tracker->R[j], tracker->t[j]);       // float round trip (quirk Q7)
-        local_feats3d.push_back(f3d);
+        local_feats3d.push_back(std::move(f3d));
     }
+    delete hps;
     std::vector<int> inliers;
     const int m = (int)(obj_points.size() / 3);
     tracker->stats.pnp_calls++; tracker->stats.pnp_points += m;
@@ -131,6 +134,7 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
         tracker->stats.t_pnp_kernel += std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count();
     }
     rodrigues_v2m(_R_rod, R_out.m);
+    HostProfScope hps2(tracker->stats.hp.t[1]);
     // Removing RANSAC outliers (:40-49)
     std::vector<uint8_t> is_inlier(m, 0);
     for (int i : inliers) if (i >= 0 && i < m) is_inlier[i] = 1;
@@ -151,9 +155,10 @@ void BundleAdjustmentBase::apply(Frame& f) {
     std::vector<double> tr_opt;                 // 6 per window frame
     std::vector<double> obs;                    // 2 per residual block
     std::vector<int> obs_cam, obs_pt;
-    std::unordered_map<std::shared_ptr<Feature3D>, int> p3d_index;
+    const unsigned epoch = ++epoch_counter;   // p3d_index of the reference, as epoch-stamped arrays over the landmark ids
     std::vector<std::shared_ptr<Feature3D>> p3d_ptr;
     std::vector<double> p3d_opt;
+    HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[2]);
     for (int i = fn - n; i < fn; i++) {
         if (i == 0) continue;
         std::shared_ptr<Frame> frame = tracker->frames[i];
@@ -165,18 +170,21 @@ void BundleAdjustmentBase::apply(Frame& f) {
         tr_opt.push_back(rod[0]); tr_opt.push_back(rod[1]); tr_opt.push_back(rod[2]);
         tr_opt.push_back(-tracker->t[i].v[0]); tr_opt.push_back(-tracker->t[i].v[1]); tr_opt.push_back(-tracker->t[i].v[2]);
         for (auto& p : frame->map) {
-            if (p.second.expired()) continue;
             std::shared_ptr<Feature3D> f3d = p.second.lock();
-            std::shared_ptr<Feature> ft = p.first;
+            if (!f3d) continue;
+            const Feature* ft = p.first.get();
             obs.push_back((double)ft->column); obs.push_back((double)ft->row);
-            auto it = p3d_index.find(f3d);
+            // index of the landmark in first-seen order (p3d_opt of the reference); landmark ids are dense creation numbers
+            const size_t lid = (size_t)f3d->id;
+            if (lid >= seen_epoch.size()) { seen_epoch.resize(lid + 4096, 0); seen_index.resize(lid + 4096, 0); }
             int pi;
-            if (it == p3d_index.end()) {
+            if (seen_epoch[lid] != epoch) {
+                seen_epoch[lid] = epoch;
                 pi = (int)p3d_ptr.size();
-                p3d_index[f3d] = pi;
-                p3d_ptr.push_back(f3d);
+                seen_index[lid] = pi;
                 p3d_opt.push_back(f3d->x); p3d_opt.push_back(f3d->y); p3d_opt.push_back(f3d->z);
-            } else pi = it->second;
+                p3d_ptr.push_back(std::move(f3d));
+            } else pi = seen_index[lid];
             obs_cam.push_back(ci); obs_pt.push_back(pi);
         }
     }
@@ -192,6 +200,7 @@ void BundleAdjustmentBase::apply(Frame& f) {
             if (used[c]) { remap[c] = nc++; for (int k = 0; k < 6; k++) cams_c.push_back(tr_opt[c * 6 + k]); }
         for (int& c : obs_cam) c = remap[c];
     }
+    delete hpg;
     tracker->stats.ba_calls++; tracker->stats.ba_obs += n_obs; tracker->stats.ba_points += (long)p3d_ptr.size();
     if (n_obs > 0) {
         const auto k0 = std::chrono::steady_clock::now();
@@ -199,6 +208,7 @@ void BundleAdjustmentBase::apply(Frame& f) {
                  tracker->camera, 1.0, tracker->cfg.ba_iterations);
         tracker->stats.t_ba_kernel += std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count();
     }
+    HostProfScope hpsc(tracker->stats.hp.t[3]);
     for (size_t c = 0; c < cam_frame.size(); c++)
         if (remap[c] >= 0) for (int k = 0; k < 6; k++) tr_opt[c * 6 + k] = cams_c[remap[c] * 6 + k];
     // Updating 3D points and camera poses (:67-88)
@@ -209,8 +219,10 @@ void BundleAdjustmentBase::apply(Frame& f) {
         rodrigues_v2m(rod, _R.m);
         tracker->R[i] = _R.t();
         tracker->t[i] = Vec3{{-tr_opt[c * 6 + 3], -tr_opt[c * 6 + 4], -tr_opt[c * 6 + 5]}};
-        for (size_t p = 0; p < p3d_ptr.size(); p++) p3d_ptr[p]->update(p3d_opt[p * 3], p3d_opt[p * 3 + 1], p3d_opt[p * 3 + 2]);
     }
+    // (the reference repeats this loop once per window frame; Feature3D::update is a plain assignment, once is identical)
+    if (!cam_frame.empty())
+        for (size_t p = 0; p < p3d_ptr.size(); p++) p3d_ptr[p]->update(p3d_opt[p * 3], p3d_opt[p * 3 + 1], p3d_opt[p * 3 + 2]);
 }
 
 // ---- OdometryPipeline ------------------------------------------------------------------------------------------------
@@ -327,8 +339,10 @@ void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
     Vec3 _t = t[j];
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+    int n3d;
+    { HostProfScope h(stats.hp.t[7]); n3d = src.count3DPoints(); }
     const auto t0 = tnow();
-    if (src.count3DPoints() >= cfg.tracked_features_tol) {
+    if (n3d >= cfg.tracked_features_tol) {
         pnpsolver->solvePnP(src, next, _R, _t);
         stats.t_pnp += secs(t0);
     } else {
@@ -336,7 +350,7 @@ void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
         stats.tri_calls++;
         stats.t_tri += secs(t0);
     }
-    motionHeuristics(_R, _t, j);
+    { HostProfScope h(stats.hp.t[6]); motionHeuristics(_R, _t, j); }
     // (frames[src.frame], frames[next.frame] are updated in place; the reference works on copies and writes them back)
     if (cfg.bundle_size && src.frame && src.frame % (cfg.bundle_size / 3 * 2) == 0) {
         const auto t1 = tnow();

@@ -84,6 +84,26 @@ public:
     virtual void ba_solve(double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
                           const int* pt_idx, int n_obs, const double* K, double huber, int max_iterations) = 0;
     void apply(Frame& src) override;
+private:
+    std::vector<unsigned> seen_epoch;   // per landmark id: the apply() call that last saw it / its index in that call
+    std::vector<int> seen_index;
+    unsigned epoch_counter = 0;
+};
+
+// optional section timers of the host adapters (PMV_HOST_PROF=1 prints them to stderr at the end of a run)
+struct HostProf {
+    static constexpr int N = 12;
+    double t[N] = {0};
+    static const char* name(int i) {
+        static const char* n[N] = {"pnp_gather", "pnp_scatter", "ba_gather", "ba_scatter", "tri_gather", "tri_landmarks", "heuristics",
+                                   "count3d", "-", "-", "-", "-"};
+        return n[i];
+    }
+};
+struct HostProfScope {
+    double& acc; std::chrono::steady_clock::time_point t0;
+    explicit HostProfScope(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~HostProfScope() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
 // per-call statistics for the bench (not part of any result)
@@ -92,7 +112,8 @@ struct Stats {
     long heuristic_motion = 0;
     // wall time per stage as seen by the calling host thread (adapter gather/scatter + plugin kernel + sync)
     double t_lk = 0, t_detect = 0, t_pnp = 0, t_tri = 0, t_ba = 0, t_pnp_kernel = 0, t_ba_kernel = 0;
-    double t_tri_essential = 0, t_tri_pose = 0, tri_hypotheses = 0;   // inside t_tri: five-point RANSAC, recoverPose; RANSAC samples drawn
+    double t_tri_essential = 0, t_tri_pose = 0, tri_hypotheses = 0;
+    HostProf hp;   // inside t_tri: five-point RANSAC, recoverPose; RANSAC samples drawn
 };
 
 class OdometryPipeline {

@@ -62,8 +62,8 @@ public:
 
     struct Hasher {   // Feature.h:28-48
         std::size_t operator()(const std::weak_ptr<Feature>& f) const {
-            if (f.expired()) return 0;
-            std::shared_ptr<Feature> p = f.lock();
+            const std::shared_ptr<Feature> p = f.lock();   // one atomic round trip instead of expired() + lock()
+            if (!p) return 0;
             return coord_hash(p->column) ^ (coord_hash(p->row) << 1);
         }
         std::size_t operator()(const std::shared_ptr<Feature>& f) const {
@@ -73,8 +73,10 @@ public:
     // Feature.cpp:48-55: coordinate equality for weak_ptr keys (expired keys never compare equal)
     struct WeakEq {
         bool operator()(const std::weak_ptr<Feature>& a, const std::weak_ptr<Feature>& b) const {
-            if (a.expired() || b.expired()) return false;
-            std::shared_ptr<Feature> pa = a.lock(), pb = b.lock();
+            const std::shared_ptr<Feature> pa = a.lock();
+            if (!pa) return false;
+            const std::shared_ptr<Feature> pb = b.lock();
+            if (!pb) return false;
             return pa->column == pb->column && pa->row == pb->row;
         }
     };
