@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=150, help="bounded sample for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--sequential", action="store_true", help="one host thread instead of front-end/back-end threads")
+    ap.add_argument("--tri-threads", type=int, default=8, help="host threads evaluating the triangulator's five-point RANSAC hypotheses (single-sequence leg)")
     ap.add_argument("--batch", type=int, default=8, help="extra leg: B independent sequences concurrently on the GPU (0 = skip)")
     args = ap.parse_args()
 
@@ -69,10 +70,12 @@ def main():
     ctx = pmv.Context(w, h, n_slots=n, max_tracks=4096, max_ba_cams=32, max_ba_points=8192, max_ba_obs=65536, device=local_rank)
     ctx.frames_stage(0, frames)   # inputs resident in HBM before the timed region
 
+    tri_threads = 1 if args.sequential else max(1, min(args.tri_threads, ncpu - 2))
+
     def step():
         return ctx.pipeline_run(n, w, h, K, gt, min_tracked=wl["min_tracked"], tol=wl["tol"], init_frames=wl["init_frames"],
                                 bundle_size=wl["bundle_size"], ba_iterations=wl["ba_iterations"], threaded=0 if args.sequential else 1,
-                                build_pyramids=1, want_features=False)
+                                build_pyramids=1, want_features=False, n_threads=tri_threads)
 
     def sync_all():
         ctx.sync()
@@ -211,7 +214,7 @@ def main():
         "dtype": "u8/int32 front-end, f64 back-end", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: synthetic KITTI-07-like sequence {w}x{h}, {n} frames, 400 tracks (tol 150), "
                                f"bundle_size 5, 5 LM iterations, init_frames 5, GFTT+LK+EPnP-RANSAC+BA; one sequence per GPU",
-                   "frames_per_step": frames_per_step, "host_threads": 1 if args.sequential else 2},
+                   "frames_per_step": frames_per_step, "host_threads": 1 if args.sequential else 2 + (tri_threads - 1)},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "batched": batched,

@@ -77,7 +77,7 @@ void* orc_pipeline_run(const vo::PipelineParams* P, const uint8_t* frames, const
     run->owned_ex.push_back(ex);
     auto* lk = new CpuLK(); lk->nthreads = P->n_threads;
     auto* pnp = new CpuPnP(); pnp->tracker = &run->pipe;
-    auto* tri = new vo::FivePointTri(); tri->tracker = &run->pipe;
+    auto* tri = new vo::FivePointTri(); tri->tracker = &run->pipe; tri->workers = std::max(1, std::min(P->n_threads, 8));
     auto* ba = new CpuBA(); ba->tracker = &run->pipe;
     run->m = lk; run->p = pnp; run->tr = tri; run->b = ba;
     run->pipe.extractor = ex; run->pipe.matcher = lk; run->pipe.pnpsolver = pnp; run->pipe.triangulator = tri; run->pipe.ba = ba;

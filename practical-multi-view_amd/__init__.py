@@ -313,10 +313,11 @@ class Context:
 
     # ---- whole sequence (OdometryPipeline role) ----
     def pipeline_run(self, n_frames, w, h, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5,
-                     ba_iterations=5, extractor=0, threaded=0, build_pyramids=1, want_features=True):
-        """frames 0..n_frames-1 must be staged in slots 0..n_frames-1 (frames_stage)"""
+                     ba_iterations=5, extractor=0, threaded=0, build_pyramids=1, want_features=True, n_threads=1):
+        """frames 0..n_frames-1 must be staged in slots 0..n_frames-1 (frames_stage); n_threads: host threads that evaluate the
+        five-point RANSAC hypotheses of the triangulator side by side (the results do not depend on it)"""
         P = PipelineParams(n_frames, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
-                           0, build_pyramids)
+                           n_threads, build_pyramids)
         Kd = np.ascontiguousarray(K, np.float64).reshape(9)
         gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n_frames, 12)
         out = C.c_void_p()

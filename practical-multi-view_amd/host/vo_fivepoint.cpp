@@ -14,6 +14,10 @@
 #include <thread>
 
 #include <chrono>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
+#include <atomic>
 namespace vo {
 namespace {
 
@@ -272,9 +276,65 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) 
 
 }  // namespace
 
+// Helper threads for the five-point RANSAC: the hypotheses of a batch are independent, so they are evaluated side by side and
+// the sequential bookkeeping (best-so-far, adaptive iteration count) is replayed in sample order afterwards — the outcome is
+// the sequential algorithm's, whatever the thread count. Workers sleep between calls and spin only while a call is active.
+class SpinPool {
+public:
+    explicit SpinPool(int workers) {
+        for (int i = 0; i < workers; i++) th_.emplace_back([this] { worker(); });
+    }
+    ~SpinPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_.store(true); active_.store(true); }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void begin() { { std::lock_guard<std::mutex> lk(mu_); active_.store(true, std::memory_order_release); } cv_.notify_all(); }
+    void end() { active_.store(false, std::memory_order_release); }
+    // runs fn(0..n-1) on the workers and the calling thread; returns when all are done
+    void run(int n, const std::function<void(int)>& fn) {
+        fn_ = &fn; ntask_ = n;
+        done_.store(0, std::memory_order_relaxed);
+        next_.store(0, std::memory_order_release);   // a worker still leaving the previous batch may take a ticket of this one
+        epoch_.fetch_add(1, std::memory_order_release);
+        drain(epoch_.load(std::memory_order_relaxed));
+        while (done_.load(std::memory_order_acquire) < n) { /* spin: the tasks are microseconds long */ }
+    }
+private:
+    void drain(unsigned e) {
+        for (;;) {
+            if (epoch_.load(std::memory_order_acquire) != e) return;   // a late worker must not touch the next batch's counters
+            const int t = next_.fetch_add(1, std::memory_order_acq_rel);
+            if (t >= ntask_) break;
+            (*fn_)(t);
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void worker() {
+        unsigned seen = epoch_.load();
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [this] { return active_.load(); }); }
+            if (stop_.load()) return;
+            while (active_.load(std::memory_order_acquire)) {
+                if (stop_.load(std::memory_order_relaxed)) return;
+                const unsigned e = epoch_.load(std::memory_order_acquire);
+                if (e != seen) { seen = e; drain(e); }
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<bool> active_{false}, stop_{false};
+    std::atomic<unsigned> epoch_{0};
+    std::atomic<int> next_{0}, done_{0};
+    int ntask_ = 0;
+    const std::function<void(int)>* fn_ = nullptr;
+};
+
 // cv::findEssentialMat(points1, points2, K, RANSAC, prob, threshold, mask): returns false when no model was found
 bool find_essential_mat(const double* p1, const double* p2, int n, const double* K, double prob, double threshold,
-                        double* E, std::vector<uint8_t>& mask, int* samples_drawn = nullptr) {
+                        double* E, std::vector<uint8_t>& mask, int* samples_drawn = nullptr, SpinPool* pool = nullptr, int pool_width = 1) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     std::vector<double> q1(2 * n), q2(2 * n);
     for (int i = 0; i < n; i++) {
@@ -311,9 +371,7 @@ bool find_essential_mat(const double* p1, const double* p2, int n, const double*
         mask.assign(n, 1);
         return true;
     }
-    for (int iter = 0; iter < niters; iter++) {
-        if (samples_drawn) ++*samples_drawn;
-        int idx[5];
+    auto draw = [&](int* idx) {   // RANSACPointSetRegistrator::getSubset: 5 distinct indices
         for (int i = 0; i < modelPoints;) {
             int idx_i;
             for (;;) {
@@ -324,11 +382,57 @@ bool find_essential_mat(const double* p1, const double* p2, int n, const double*
             }
             i++;
         }
-        double s1[10], s2[10];
-        for (int i = 0; i < 5; i++) { s1[2 * i] = q1[2 * idx[i]]; s1[2 * i + 1] = q1[2 * idx[i] + 1]; s2[2 * i] = q2[2 * idx[i]]; s2[2 * i + 1] = q2[2 * idx[i] + 1]; }
-        const int nm = five_point_kernel(s1, s2, models);
-        if (nm <= 0) continue;
-        evaluate(nm);
+    };
+    if (!pool || pool_width <= 1) {
+        for (int iter = 0; iter < niters; iter++) {
+            if (samples_drawn) ++*samples_drawn;
+            int idx[5];
+            draw(idx);
+            double s1[10], s2[10];
+            for (int i = 0; i < 5; i++) { s1[2 * i] = q1[2 * idx[i]]; s1[2 * i + 1] = q1[2 * idx[i] + 1]; s2[2 * i] = q2[2 * idx[i]]; s2[2 * i + 1] = q2[2 * idx[i] + 1]; }
+            const int nm = five_point_kernel(s1, s2, models);
+            if (nm <= 0) continue;
+            evaluate(nm);
+        }
+    } else {
+        // batches of independent hypotheses on the helper threads, then the sequential bookkeeping in sample order
+        const int B = std::min(64, 3 * pool_width);
+        struct Hyp { int idx[5]; int nm; double models[90]; int good[10]; };
+        std::vector<Hyp> hyp(B);
+        std::vector<std::vector<float>> errs(B, std::vector<float>(n));
+        pool->begin();
+        int iter = 0;
+        while (iter < niters) {
+            const int nb = std::min(B, niters - iter);
+            for (int b = 0; b < nb; b++) draw(hyp[b].idx);   // the index stream is sequential
+            const std::function<void(int)> task = [&](int b) {
+                Hyp& h = hyp[b];
+                double s1[10], s2[10];
+                for (int i = 0; i < 5; i++) { s1[2 * i] = q1[2 * h.idx[i]]; s1[2 * i + 1] = q1[2 * h.idx[i] + 1]; s2[2 * i] = q2[2 * h.idx[i]]; s2[2 * i + 1] = q2[2 * h.idx[i] + 1]; }
+                h.nm = five_point_kernel(s1, s2, h.models);
+                for (int mi = 0; mi < h.nm; mi++) {
+                    sampson_errors(h.models + 9 * mi, q1.data(), q2.data(), n, errs[b].data());
+                    int good = 0;
+                    for (int i = 0; i < n; i++) good += errs[b][i] <= thr;
+                    h.good[mi] = good;
+                }
+            };
+            pool->run(nb, task);
+            for (int b = 0; b < nb && iter < niters; b++, iter++) {
+                if (samples_drawn) ++*samples_drawn;
+                const Hyp& h = hyp[b];
+                for (int mi = 0; mi < h.nm; mi++) {
+                    if (h.good[mi] > std::max(maxGood, modelPoints - 1)) {
+                        sampson_errors(h.models + 9 * mi, q1.data(), q2.data(), n, err.data());
+                        for (int i = 0; i < n; i++) mask[i] = (uint8_t)(err[i] <= thr);
+                        memcpy(best, h.models + 9 * mi, sizeof(best));
+                        maxGood = h.good[mi];
+                        niters = ransac_update_num_iters(prob, (double)(n - maxGood) / n, modelPoints, niters);
+                    }
+                }
+            }
+        }
+        pool->end();
     }
     if (maxGood <= 0) { mask.assign(n, 0); return false; }
     memcpy(E, best, sizeof(best));
@@ -429,6 +533,10 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     const int j = src.frame;
     std::vector<double> p1, p2;
     std::vector<std::shared_ptr<Feature>> p1_ptr, p2_ptr;
+    if (workers > 1) {   // wake the helper threads now: they are spinning by the time the gather below is done
+        if (!pool) pool = std::make_shared<SpinPool>(workers - 1);
+        pool->begin();
+    }
     HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[4]);
     for (auto& p : src.feat_corr) {
         if (p.first.expired() || p.second.expired()) continue;
@@ -446,7 +554,8 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     double E[9];
     int drawn = 0;
     auto tE = std::chrono::steady_clock::now();
-    const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn);
+    const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn, pool.get(), workers);
+    if (pool) pool->end();
     tracker->stats.t_tri_essential += std::chrono::duration<double>(std::chrono::steady_clock::now() - tE).count();
     tracker->stats.tri_hypotheses += drawn;
     if (!ok) {

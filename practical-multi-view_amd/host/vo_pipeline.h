@@ -67,9 +67,12 @@ public:
 void dlt_candidates_host(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
                          uint8_t* out_mask, int* out_good);
 
+class SpinPool;
 class FivePointTri : public BaseTriangulator {                   // OpenCVFivePointTri
 public:
     OdometryPipeline* tracker = nullptr;
+    int workers = 1;                 // threads evaluating RANSAC hypotheses side by side (results do not depend on it)
+    std::shared_ptr<SpinPool> pool;  // created on first use when workers > 1
     void triangulate(Frame& src, Frame& next, Mat3& R, Vec3& t) override;
     // kernel hook (same contract as dlt_candidates_host); the HIP plugin overrides it with pmv_triangulate_candidates
     virtual void dlt_candidates(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
