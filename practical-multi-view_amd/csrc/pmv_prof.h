@@ -11,10 +11,12 @@ enum KernelId { K_PAD0 = 0, K_PYRDOWN, K_LK, K_GFTT_EIG, K_GFTT_SELECT, K_ST_RES
 
 inline const char* kernel_name(int id) {
     static const char* n[K_COUNT] = {"k_pad_level0", "k_pyrdown", "k_lk", "k_gftt_eig", "k_gftt_select", "k_st_resp", "k_st_select",
-                                     "k_pnp_hyp", "k_pnp_select_refit", "k_ba_lm", "k_ba_residuals", "k_tri_dlt"};
+                                     "k_pnp_hyp", "k_pnp_select_refit", "ba_lm_chain", "k_ba_residuals", "k_tri_dlt"};
     return (id >= 0 && id < K_COUNT) ? n[id] : "?";
 }
 
+// "ba_lm_chain" times one whole LM solve: the chain of k_bam_* launches (or k_ba_lm in single-workgroup mode); every other
+// class is exactly one kernel per launch.
 struct Profiler {
     static constexpr int CAP = 8192;   // launches per kernel class between resets
     bool enabled = false;
