@@ -16,6 +16,7 @@ struct BAArgs {
     double *x, *cand, *scale, *diag, *D2, *step, *res, *J, *Einv, *gp, *Yd, *Wd, *S, *rhs, *Gpart, *summary;
     int ldw, krows, tiles_r, tiles_c, kslices, kper, gp_rows;
     unsigned long long* stamps;   // optional (diagnostic): 32 accumulated shader-clock phase timers
+    double* out;                  // optional: host-mapped result block [summary 8 | cams 6*nc | pts 3*np] (multi-kernel LM)
 };
 
 hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,
@@ -26,7 +27,8 @@ constexpr int BA_MAX_ITERATIONS = 512;   // per-iteration flags of the multi-ker
 hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double* d_part);
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
-                      double* d_rt_out, int* d_inliers, int* d_info, unsigned long long* d_stamps /* diagnostic, may be null */);
+                      double* d_rt_out, int* d_inliers, int* d_info, char* host_out /* mapped pinned [rt 48 B | info 16 B | inliers] */,
+                      unsigned long long* d_stamps /* diagnostic, may be null */);
 
 hipError_t launch_tri_dlt(hipStream_t s, const double* d_P1x4, const double* d_q1, const double* d_q2, const uint8_t* d_mask_in, int n,
                           double* d_Q, uint8_t* d_mask);

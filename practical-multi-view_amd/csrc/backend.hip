@@ -24,6 +24,7 @@ struct BackendBuffers {
     void* d_bastate = nullptr;
     double* d_bapart = nullptr;
     char *d_tri_in = nullptr, *d_tri_out = nullptr;
+    char* d_h_stage = nullptr;   // device address of the pinned staging block: result blocks are written straight into it
     size_t tri_in_bytes = 0, tri_out_bytes = 0;
     // single-copy transfers: one pinned staging block and one device block per direction
     void* h_stage = nullptr;
@@ -90,7 +91,8 @@ int backend_create(pmv_ctx* c) {
     b->h_stage_bytes = std::max(b->h_stage_bytes, std::max(b->ba_io_bytes, b->pnp_in_bytes + b->pnp_out_bytes));
     b->h_stage_bytes = std::max(b->h_stage_bytes, b->tri_in_bytes + b->tri_out_bytes);
     (void)hipHostFree(b->h_stage);
-    CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes));
+    CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes, hipHostMallocMapped));
+    CKB(hipHostGetDevicePointer((void**)&b->d_h_stage, b->h_stage, 0));
 #undef CKB
     return PMV_OK;
 }
@@ -179,11 +181,10 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     int* d_info = (int*)(b->d_pnp_out + 48);
     int* d_inl = (int*)(b->d_pnp_out + 64);
     const float thr = (float)((double)reproj_err * (double)reproj_err);
-    CKC(launch_pnp(s, d_obj, d_img, m, d_K, d_samples, iterations, thr, confidence, b->d_models, b->d_masks, b->d_counts,
-                   d_rt, d_inl, d_info, getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr));
     char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
-    CKC(hipMemcpyAsync(ho, b->d_pnp_out, 64 + (size_t)m * 4, hipMemcpyDeviceToHost, s));
-    CKC(hipStreamSynchronize(s));
+    CKC(launch_pnp(s, d_obj, d_img, m, d_K, d_samples, iterations, thr, confidence, b->d_models, b->d_masks, b->d_counts,
+                   d_rt, d_inl, d_info, b->d_h_stage + (ho - hs), getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr));
+    CKC(hipStreamSynchronize(s));   // the refit kernel wrote [rt | info | inliers] straight into the pinned block
     const double* h_rt = (const double*)ho;
     const int* h_info = (const int*)(ho + 48);
     const int* h_inl = (const int*)(ho + 64);
@@ -308,6 +309,7 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     A.x = b->d_x; A.cand = b->d_cand; A.scale = b->d_scale; A.diag = b->d_diag; A.D2 = b->d_D2; A.step = b->d_step; A.res = b->d_res; A.J = b->d_J;
     A.Einv = b->d_Einv; A.gp = b->d_gp; A.Yd = b->d_Yd; A.Wd = b->d_Wd; A.S = b->d_S; A.rhs = b->d_rhs; A.Gpart = b->d_Gpart; A.summary = d_sum;
     A.stamps = getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr;
+    A.out = nullptr;
     A.tiles_r = tiles_r; A.tiles_c = tiles_c;
     A.ldw = A.tiles_c * 16;
     A.krows = round_up(3 * np, 16);
@@ -328,10 +330,11 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     if (single) CKC(launch_ba_lm(s, A));
     else {
         A.Wd = A.Yd + (size_t)A.krows * A.ldw;
+        A.out = (double*)b->d_h_stage;   // [summary 8 | cams | pts] of the result, straight into the pinned block
         CKC(launch_ba_multi(s, A, b->d_bastate, b->d_bapart));
     }
     const size_t out_bytes = (8 + (size_t)nc * 6 + (size_t)np * 3) * 8;
-    CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));
+    if (single) CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));   // (multi: the finish kernel wrote into hs)
     CKC(hipStreamSynchronize(s));
     const double* h_out = (const double*)hs;
     if (!single && check) {   // diagnostic: the same problem through the one-workgroup kernel, differences to stderr
@@ -402,12 +405,10 @@ int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2,
     const double* d_q1 = d_P + 48;
     const double* d_q2 = d_q1 + (size_t)2 * n;
     const uint8_t* d_m = (const uint8_t*)(d_q2 + (size_t)2 * n);
-    double* d_Q = (double*)b->d_tri_out;
+    char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
+    double* d_Q = (double*)(b->d_h_stage + (ho - hs));   // results go straight into the pinned block (coalesced 8-byte stores)
     uint8_t* d_mask = (uint8_t*)(d_Q + (size_t)16 * n);
     CKC(launch_tri_dlt(s, d_P, d_q1, d_q2, d_m, n, d_Q, d_mask));
-    char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
-    const size_t out_bytes = (size_t)16 * n * 8 + (size_t)4 * n;
-    CKC(hipMemcpyAsync(ho, b->d_tri_out, out_bytes, hipMemcpyDeviceToHost, s));
     CKC(hipStreamSynchronize(s));
     memcpy(out_Q, ho, (size_t)16 * n * 8);
     memcpy(out_mask, ho + (size_t)16 * n * 8, (size_t)4 * n);

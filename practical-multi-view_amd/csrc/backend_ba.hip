@@ -1480,11 +1480,14 @@ __device__ inline void bam_finish_role(const BAArgs& A, const BAGState* __restri
     __syncthreads();
     const int n = 6 * A.nc + 3 * A.np;
     const double* x = A.x + (size_t)ss.cur * n;
-    for (int i = threadIdx.x; i < 6 * A.nc; i += BM_T) A.cams[i] = x[i];
-    for (int i = threadIdx.x; i < 3 * A.np; i += BM_T) A.pts[i] = x[6 * A.nc + i];
+    double* ocams = A.out ? A.out + 8 : A.cams;
+    double* opts = A.out ? A.out + 8 + 6 * A.nc : A.pts;
+    double* osum = A.out ? A.out : A.summary;
+    for (int i = threadIdx.x; i < 6 * A.nc; i += BM_T) ocams[i] = x[i];
+    for (int i = threadIdx.x; i < 3 * A.np; i += BM_T) opts[i] = x[6 * A.nc + i];
     if (threadIdx.x == 0) {
-        A.summary[0] = ss.initial_cost; A.summary[1] = ss.x_cost; A.summary[2] = ss.iter; A.summary[3] = ss.successful;
-        A.summary[4] = ss.termination;
+        osum[0] = ss.initial_cost; osum[1] = ss.x_cost; osum[2] = ss.iter; osum[3] = ss.successful;
+        osum[4] = ss.termination;
     }
 }
 

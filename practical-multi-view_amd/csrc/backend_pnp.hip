@@ -504,7 +504,7 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
                                                            const double* __restrict__ K, const double* __restrict__ models,
                                                            const uint8_t* __restrict__ masks, const int* __restrict__ counts,
                                                            int n_hyp, double confidence, double* __restrict__ rt_out,
-                                                           int* __restrict__ inliers, int* __restrict__ info) {
+                                                           int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out) {
     __shared__ RefitShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) {
@@ -528,6 +528,10 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
             info[0] = 0;
             const int l = sh.last < 0 ? 0 : sh.last;
             for (int i = 0; i < 6; i++) rt_out[i] = models[l * 6 + i];
+            if (host_out) {
+                for (int i = 0; i < 6; i++) ((double*)host_out)[i] = models[l * 6 + i];
+                ((int*)(host_out + 48))[0] = 0; ((int*)(host_out + 48))[1] = sh.last + 1;
+            }
         }
         return;
     }
@@ -667,16 +671,22 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
         if (sh.done) break;
     }
     if (tid < 6) rt_out[tid] = sh.param[tid];
+    if (host_out) {   // the result block in mapped pinned host memory: no device-to-host copy afterwards
+        if (tid < 6) ((double*)host_out)[tid] = sh.param[tid];
+        if (tid == 0) { ((int*)(host_out + 48))[0] = n; ((int*)(host_out + 48))[1] = sh.last + 1; }
+        int* hin = (int*)(host_out + 64);
+        for (int e = tid; e < n; e += RF_T) hin[e] = inliers[e];
+    }
 }
 
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
-                      double* d_rt_out, int* d_inliers, int* d_info, unsigned long long* d_stamps) {
+                      double* d_rt_out, int* d_inliers, int* d_info, char* host_out, unsigned long long* d_stamps) {
     { ProfScope ps(K_PNP_HYP, s);
     hipLaunchKernelGGL(k_pnp_hyp, dim3(n_hyp), dim3(64), 0, s, d_obj, d_img, d_samples, d_K, d_models, m, thr, d_masks, d_counts, d_stamps); }
     ProfScope ps3(K_PNP_REFIT, s);
     hipLaunchKernelGGL(k_pnp_select_refit, dim3(1), dim3(RF_T), 0, s, d_obj, d_img, m, d_K, d_models, d_masks, d_counts, n_hyp,
-                       confidence, d_rt_out, d_inliers, d_info);
+                       confidence, d_rt_out, d_inliers, d_info, host_out);
     return hipGetLastError();
 }
 
