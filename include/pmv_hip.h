@@ -122,6 +122,7 @@ int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2,
 
 /* ---- per-kernel timing (HIP events on the launching stream; used by bench.py for the roofline object) -------------- */
 int pmv_prof_enable(pmv_ctx* ctx, int on);  /* on != 0: reset counters and start recording; 0: stop */
+int pmv_prof_select(pmv_ctx* ctx, unsigned mask); /* after pmv_prof_enable(1): record only classes whose bit (= id) is set */
 int pmv_prof_kernel_count(void);
 const char* pmv_prof_kernel_name(int id);
 int pmv_prof_read(pmv_ctx* ctx, int id, int* launches, double* total_ms, double* max_ms);
@@ -145,6 +146,9 @@ typedef struct pmv_pipeline_result pmv_pipeline_result;
 int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* params, const double* K9, const double* gt_poses12,
                      pmv_pipeline_result** out);
 void pmv_pipeline_free(pmv_pipeline_result* r);
+/* Same, but the (host-container) teardown runs on a background thread; pmv_pipeline_drain() joins all of them. */
+void pmv_pipeline_release(pmv_pipeline_result* r);
+void pmv_pipeline_drain(void);
 int pmv_pipeline_num_poses(const pmv_pipeline_result* r);
 void pmv_pipeline_get_poses(const pmv_pipeline_result* r, double* out12); /* per pose: R row-major (9) then t (3) */
 int pmv_pipeline_num_frames(const pmv_pipeline_result* r);

@@ -37,8 +37,8 @@ ABI_SYMBOLS = [
     "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frame_get_level", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates",
-    "pmv_prof_enable", "pmv_prof_kernel_count", "pmv_prof_kernel_name", "pmv_prof_read",
-    "pmv_pipeline_run", "pmv_pipeline_free", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
+    "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_prof_kernel_name", "pmv_prof_read",
+    "pmv_pipeline_run", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
     "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_get_stats",
 ]
 
@@ -74,6 +74,20 @@ class PipelineResult:
         st = np.zeros(24, np.float64)
         lib.pmv_pipeline_get_stats(handle, _p(st, _f64p))
         self.stats = dict(zip(STAT_KEYS, [float(v) for v in st[:len(STAT_KEYS)]]))
+        self._deferred = None   # (lib, handle) when the caller asked to free the native result later (defer_free)
+
+    def free(self):
+        """frees the native result of a pipeline_run(..., defer_free=True) call (idempotent)"""
+        if self._deferred:
+            lib, handle = self._deferred
+            self._deferred = None
+            lib.pmv_pipeline_free(handle)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 _lib = None
@@ -97,6 +111,10 @@ def load_library():
         if hasattr(_lib, "pmv_pipeline_run"):
             _lib.pmv_pipeline_run.argtypes = [C.c_void_p, C.POINTER(PipelineParams), _f64p, _f64p, C.POINTER(C.c_void_p)]
             _lib.pmv_pipeline_free.argtypes = [C.c_void_p]
+            _lib.pmv_pipeline_release.argtypes = [C.c_void_p]
+            _lib.pmv_pipeline_release.restype = None
+            _lib.pmv_pipeline_drain.argtypes = []
+            _lib.pmv_pipeline_drain.restype = None
             _lib.pmv_pipeline_num_poses.argtypes = [C.c_void_p]
             _lib.pmv_pipeline_get_poses.argtypes = [C.c_void_p, _f64p]
             _lib.pmv_pipeline_num_frames.argtypes = [C.c_void_p]
@@ -300,6 +318,15 @@ class Context:
     def prof_enable(self, on=True):
         self._ck(self.lib.pmv_prof_enable(self.h, 1 if on else 0))
 
+    def prof_select(self, names):
+        """after prof_enable(True): record only the named kernel classes"""
+        self.lib.pmv_prof_kernel_name.restype = C.c_char_p
+        mask = 0
+        for i in range(self.lib.pmv_prof_kernel_count()):
+            if self.lib.pmv_prof_kernel_name(i).decode() in names:
+                mask |= 1 << i
+        self._ck(self.lib.pmv_prof_select(self.h, C.c_uint(mask)))
+
     def prof_read(self):
         """{kernel: (launches, total_ms, max_ms)} for every kernel class launched since prof_enable(True)"""
         self.lib.pmv_prof_kernel_name.restype = C.c_char_p
@@ -313,7 +340,8 @@ class Context:
 
     # ---- whole sequence (OdometryPipeline role) ----
     def pipeline_run(self, n_frames, w, h, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5,
-                     ba_iterations=5, extractor=0, threaded=0, build_pyramids=1, want_features=True, n_threads=1):
+                     ba_iterations=5, extractor=0, threaded=0, build_pyramids=1, want_features=True, n_threads=1, async_free=False,
+                     defer_free=False):
         """frames 0..n_frames-1 must be staged in slots 0..n_frames-1 (frames_stage); n_threads: host threads that evaluate the
         five-point RANSAC hypotheses of the triangulator side by side (the results do not depend on it)"""
         P = PipelineParams(n_frames, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
@@ -322,7 +350,21 @@ class Context:
         gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n_frames, 12)
         out = C.c_void_p()
         self._ck(self.lib.pmv_pipeline_run(self.h, C.byref(P), _p(Kd, _f64p), _p(gt, _f64p), C.byref(out)))
+        # Tearing down the ~10^6 host-container nodes of a long run takes ~40 ms and is not part of the path. defer_free: the
+        # caller frees later (result.free()); async_free: a background thread does it (pipeline_drain() joins).
+        ok = False
         try:
-            return PipelineResult(self.lib, out, want_features)
+            r = PipelineResult(self.lib, out, want_features)
+            ok = True
         finally:
-            self.lib.pmv_pipeline_free(out)
+            if not (ok and defer_free):
+                if async_free:
+                    self.lib.pmv_pipeline_release(out)
+                else:
+                    self.lib.pmv_pipeline_free(out)
+        if defer_free:
+            r._deferred = (self.lib, out)
+        return r
+
+    def pipeline_drain(self):
+        self.lib.pmv_pipeline_drain()

@@ -302,6 +302,14 @@ int pmv_prof_enable(pmv_ctx* ctx, int on) {
     CKC(hipStreamSynchronize(ctx->s_back));
     if (on) for (int i = 0; i < K_COUNT; i++) { ctx->prof.used[i] = 0; ctx->prof.dropped[i] = 0; }
     ctx->prof.enabled = on != 0;
+    ctx->prof.mask = ~0u;
+    return PMV_OK;
+}
+// restrict recording to the classes whose bit is set (events cost host time and a queue barrier each: the timed region of the
+// bench records only the kernel its roofline object reports)
+int pmv_prof_select(pmv_ctx* ctx, unsigned mask) {
+    REQ(ctx, PMV_ERR_INVALID, "null ctx");
+    ctx->prof.mask = mask;
     return PMV_OK;
 }
 int pmv_prof_kernel_count(void) { return K_COUNT; }

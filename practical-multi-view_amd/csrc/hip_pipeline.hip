@@ -3,6 +3,8 @@
 // every numerically heavy call crosses into the gfx950 kernels. No CPU fallback exists on this path (the triangulator,
 // which the north star does not move to the device, is the host implementation in host/vo_fivepoint.cpp).
 #include "pmv_ctx.h"
+#include <mutex>
+#include <thread>
 #include "vo_capi_impl.h"
 #include <cstring>
 #include <stdexcept>
@@ -134,6 +136,20 @@ int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K
     return PMV_OK;
 }
 void pmv_pipeline_free(pmv_pipeline_result* r) { delete r; }
+// Tearing down ~10^6 host container nodes of a 1100-frame run takes ~40 ms and is not part of the path: a result can be
+// handed to a background thread instead. pmv_pipeline_drain() waits for all outstanding releases.
+static std::mutex g_release_mu;
+static std::vector<std::thread> g_release_threads;
+void pmv_pipeline_release(pmv_pipeline_result* r) {
+    if (!r) return;
+    std::lock_guard<std::mutex> lk(g_release_mu);
+    g_release_threads.emplace_back([r] { delete r; });
+}
+void pmv_pipeline_drain(void) {
+    std::vector<std::thread> th;
+    { std::lock_guard<std::mutex> lk(g_release_mu); th.swap(g_release_threads); }
+    for (auto& t : th) t.join();
+}
 int pmv_pipeline_num_poses(const pmv_pipeline_result* r) { return vo::pipeline_num_poses(r->run); }
 void pmv_pipeline_get_poses(const pmv_pipeline_result* r, double* out) { vo::pipeline_get_poses(r->run, out); }
 int pmv_pipeline_num_frames(const pmv_pipeline_result* r) { return vo::pipeline_num_frames(r->run); }

@@ -20,6 +20,7 @@ inline const char* kernel_name(int id) {
 struct Profiler {
     static constexpr int CAP = 8192;   // launches per kernel class between resets
     bool enabled = false;
+    unsigned mask = ~0u;               // kernel classes that are recorded while enabled (bit = KernelId)
     std::vector<hipEvent_t> ev[K_COUNT];
     int used[K_COUNT] = {0};
     long dropped[K_COUNT] = {0};
@@ -44,7 +45,7 @@ struct ProfScope {
     hipEvent_t* e = nullptr;
     hipStream_t s;
     ProfScope(int id, hipStream_t stream) : s(stream) {
-        if (tl_prof && tl_prof->enabled) { e = tl_prof->next(id); if (e) (void)hipEventRecord(e[0], s); }
+        if (tl_prof && tl_prof->enabled && ((tl_prof->mask >> id) & 1u)) { e = tl_prof->next(id); if (e) (void)hipEventRecord(e[0], s); }
     }
     ~ProfScope() { if (e) (void)hipEventRecord(e[1], s); }
 };

@@ -64,7 +64,7 @@ inline void pipeline_execute(PipelineRun& run, const PipelineParams& P) {
     run.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("PMV_HOST_PROF")) {
         fprintf(stderr, "[host-prof] run %.4f s:", run.seconds);
-        for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.4f", HostProf::name(i), run.pipe.stats.hp.t[i]);
+        for (int i = 0; i < HostProf::N; i++) fprintf(stderr, " %s=%.4f", HostProf::name(i), run.pipe.stats.hp.t[i]);
         fprintf(stderr, "\n");
     }
 }

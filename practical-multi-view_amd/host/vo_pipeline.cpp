@@ -334,6 +334,7 @@ void OdometryPipeline::motionHeuristics(Mat3& _R, Vec3& _t, int j) {   // :171-2
 }
 
 void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
+    HostProfScope hp_total(stats.hp.t[8]);
     const int j = src.frame;
     Mat3 _R = R[j];
     Vec3 _t = t[j];
@@ -378,7 +379,7 @@ void OdometryPipeline::run() {   // startPipeline :247-264 + featureExtractionTh
 
 void OdometryPipeline::run_threaded() {
     for (int i = 0; i < cfg.init_frames; i++) frames.push_back(std::make_shared<Frame>(Frame(images[i])));
-    initialise();
+    { HostProfScope hp_init(stats.hp.t[11]); initialise(); }
     R.push_back(Mat3::eye()); t.push_back(Vec3{{0, 0, 0}});
     R_s.push_back(Mat3::eye()); t_s.push_back(Vec3{{0, 0, 0}});
     // job pipe (dlib::pipe<Job> in the reference). `frames` only grows at the back (front-end) while the back-end touches
@@ -393,6 +394,7 @@ void OdometryPipeline::run_threaded() {
             int j;
             std::shared_ptr<Frame> a, b;
             {
+                HostProfScope hp_wait(stats.hp.t[9]);
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !jobs.empty() || done; });
                 if (jobs.empty()) return;
@@ -402,6 +404,7 @@ void OdometryPipeline::run_threaded() {
             estimatePose(*a, *b);
         }
     });
+    const auto t_front0 = std::chrono::steady_clock::now();
     for (int i = init_offset + 1; i < (int)images.size(); i++) {
         if (i >= cfg.stop) break;
         Frame frame(images[i]);
@@ -443,6 +446,7 @@ void OdometryPipeline::run_threaded() {
         if (on_frame_added) on_frame_added(frame.frame);
     }
     { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_one(); }
+    stats.hp.t[10] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_front0).count();
     back.join();
 }
 

@@ -99,7 +99,7 @@ struct HostProf {
     double t[N] = {0};
     static const char* name(int i) {
         static const char* n[N] = {"pnp_gather", "pnp_scatter", "ba_gather", "ba_scatter", "tri_gather", "tri_landmarks", "heuristics",
-                                   "count3d", "-", "-", "-", "-"};
+                                   "count3d", "estimatePose", "backend_wait", "frontend_total", "init"};
         return n[i];
     }
 };
