@@ -26,60 +26,64 @@ struct EpnpShared {
     double case_err[3], case_R[27], case_t[9];
 };
 
-__device__ void epnp_qr_solve(double* A, double* b, double* X) {   // epnp::qr_solve, 6x4
-    const int nr = 6, nc = 4;
-    double A1[6], A2[6];
-    double* ppAkk = A;
+// epnp::qr_solve (6x4, Householder), same arithmetic in the same order as the pointer-walking original — including its
+// pivot-scale quirk: eta is the maximum over rows k..4 (the scan starts one element early and never reads the last row).
+// Every index is a compile-time constant after unrolling, so A, b, A1, A2 live in registers (the pointer version kept A in
+// scratch memory: 70 scratch accesses per call on the critical path).
+__device__ inline void epnp_qr_solve(double* A, double* b, double* X) {
+    constexpr int nr = 6, nc = 4;
+    double A1[4], A2[4];
+#pragma unroll
     for (int k = 0; k < nc; k++) {
-        double* ppAik1 = ppAkk;
-        double eta = fabs(*ppAik1);
+        double eta = fabs(A[k * nc + k]);
+#pragma unroll
         for (int i = k + 1; i < nr; i++) {
-            const double elt = fabs(*ppAik1);
+            const double elt = fabs(A[(i - 1) * nc + k]);
             if (eta < elt) eta = elt;
-            ppAik1 += nc;
         }
         if (eta == 0) { X[0] = X[1] = X[2] = X[3] = 0.0; return; }
-        double* ppAik2 = ppAkk;
         double sum2 = 0.0;
         const double inv_eta = 1. / eta;
-        for (int i = k; i < nr; i++) { *ppAik2 *= inv_eta; sum2 += *ppAik2 * *ppAik2; ppAik2 += nc; }
+#pragma unroll
+        for (int i = k; i < nr; i++) { A[i * nc + k] *= inv_eta; sum2 += A[i * nc + k] * A[i * nc + k]; }
         double sigma = sqrt(sum2);
-        if (*ppAkk < 0) sigma = -sigma;
-        *ppAkk += sigma;
-        A1[k] = sigma * *ppAkk;
+        if (A[k * nc + k] < 0) sigma = -sigma;
+        A[k * nc + k] += sigma;
+        A1[k] = sigma * A[k * nc + k];
         A2[k] = -eta * sigma;
+#pragma unroll
         for (int j = k + 1; j < nc; j++) {
-            double* ppAik = ppAkk;
             double sum = 0;
-            for (int i = k; i < nr; i++) { sum += *ppAik * ppAik[j - k]; ppAik += nc; }
+#pragma unroll
+            for (int i = k; i < nr; i++) sum += A[i * nc + k] * A[i * nc + j];
             const double tau = sum / A1[k];
-            ppAik = ppAkk;
-            for (int i = k; i < nr; i++) { ppAik[j - k] -= tau * *ppAik; ppAik += nc; }
+#pragma unroll
+            for (int i = k; i < nr; i++) A[i * nc + j] -= tau * A[i * nc + k];
         }
-        ppAkk += nc + 1;
     }
-    double* ppAjj = A;
+#pragma unroll
     for (int j = 0; j < nc; j++) {
-        double* ppAij = ppAjj;
         double tau = 0;
-        for (int i = j; i < nr; i++) { tau += *ppAij * b[i]; ppAij += nc; }
+#pragma unroll
+        for (int i = j; i < nr; i++) tau += A[i * nc + j] * b[i];
         tau /= A1[j];
-        ppAij = ppAjj;
-        for (int i = j; i < nr; i++) { b[i] -= tau * *ppAij; ppAij += nc; }
-        ppAjj += nc + 1;
+#pragma unroll
+        for (int i = j; i < nr; i++) b[i] -= tau * A[i * nc + j];
     }
     X[nc - 1] = b[nc - 1] / A2[nc - 1];
+#pragma unroll
     for (int i = nc - 2; i >= 0; i--) {
-        const double* ppAij = A + i * nc + (i + 1);
         double sum = 0;
-        for (int j = i + 1; j < nc; j++) { sum += *ppAij * X[j]; ppAij++; }
+#pragma unroll
+        for (int j = i + 1; j < nc; j++) sum += A[i * nc + j] * X[j];
         X[i] = (b[i] - sum) / A2[i];
     }
 }
 
-__device__ void epnp_gauss_newton(const double* L, const double* rho, double* betas) {
+__device__ inline void epnp_gauss_newton(const double* L, const double* rho, double* betas) {
     for (int k = 0; k < 5; k++) {
         double A[24], b[6], x[4];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             const double* rowL = L + i * 10;
             double* rowA = A + i * 4;
