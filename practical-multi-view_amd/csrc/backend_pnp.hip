@@ -469,29 +469,31 @@ __device__ inline void d_angle_axis_rotate_jac(const double a[3], const double q
 
 constexpr int RF_T = 256;
 struct RefitShared {
-    double tile[28 * 256];   // per-thread partials, [value][thread]
+    double tile[28 * (256 + 8)];   // per-thread partials, [value][thread], rows padded by 8 (bank spread)
     double part[28 * 8];
     double red[4 * 28];
-    double Aug[6 * 7];       // augmented normal equations of one LM step
     double JtJ[36], JtErr[6], param[6], prev[6];
     double err2, prevErr2;
     int best, last, n_in, state, lambdaLg10, iters, done;
     int wsum[4];
 };
 
-// sums 28 per-thread values over the block in a fixed order: LDS tile [28][256], 28 x 8 threads add 32 consecutive
-// entries each, 28 threads add the 8 partials. Result in sh.red[0..27].
+// sums 28 per-thread values over the block in a fixed order: LDS tile [28][256 (+8 pad)], 28 x 8 threads add 32 entries each
+// (entry j*8 + part: consecutive lanes read consecutive addresses, the 8-double row pad spreads the 8 values k of a wavefront
+// over different banks — a contiguous 32-entry chunk per lane put all 64 lanes on one bank), 28 threads add the 8 partials.
+// Result in sh.red[0..27].
+constexpr int RF_ROW = RF_T + 8;
 __device__ inline void block_sum28(const double* acc, RefitShared& sh) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < 28; k++) sh.tile[k * RF_T + tid] = acc[k];
+    for (int k = 0; k < 28; k++) sh.tile[k * RF_ROW + tid] = acc[k];
     __syncthreads();
     if (tid < 28 * 8) {
         const int k = tid >> 3, part = tid & 7;
-        const double* src = &sh.tile[k * RF_T + part * 32];
+        const double* src = &sh.tile[k * RF_ROW + part];
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // four independent chains (fixed order), 8 dependent adds instead of 32
 #pragma unroll
-        for (int j = 0; j < 32; j += 4) { s0 += src[j]; s1 += src[j + 1]; s2 += src[j + 2]; s3 += src[j + 3]; }
+        for (int j = 0; j < 32; j += 4) { s0 += src[8 * j]; s1 += src[8 * (j + 1)]; s2 += src[8 * (j + 2)]; s3 += src[8 * (j + 3)]; }
         sh.part[k * 8 + part] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
@@ -508,8 +510,12 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
                                                            const double* __restrict__ K, const double* __restrict__ models,
                                                            const uint8_t* __restrict__ masks, const int* __restrict__ counts,
                                                            int n_hyp, double confidence, double* __restrict__ rt_out,
-                                                           int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out) {
+                                                           int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out,
+                                                           unsigned long long* stamps) {
     __shared__ RefitShared sh;
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    unsigned long long t_lm0 = 0;
+    int n_pass = 0;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) {
         // RANSACPointSetRegistrator::run replayed over the precomputed hypotheses
@@ -564,7 +570,11 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
     __syncthreads();
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     // state 0: compute J & err at param, step; state 1: check err at new param
+    t_lm0 = __builtin_readcyclecounter();
     for (;;) {
+        n_pass++;
+        unsigned long long t_p = __builtin_readcyclecounter();
+#define RSTAMP(k) do { if (stamps && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); stamps[k] += t_ - t_p; t_p = t_; } } while (0)
         const bool jac = (sh.state == 0);
         double acc[28];
 #pragma unroll
@@ -601,7 +611,9 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
                 for (int a = 0; a < 6; a++) acc[21 + a] += Ju[a] * ex + Jv[a] * ey;
             }
         }
+        RSTAMP(10);
         block_sum28(acc, sh);
+        RSTAMP(11);
         if (tid == 0) {
             const double err2 = sh.red[27];
             bool do_step = false;
@@ -626,53 +638,66 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
                     else { sh.prevErr2 = err2; sh.state = 0; }
                 }
             }
-            sh.state = do_step ? (sh.state | 2) : sh.state;   // bit 1: a step has to be solved by wave 0 below
             if (do_step) {
+                // (JtJ + lambda diag(JtJ)) x = JtErr by Gaussian elimination with partial pivoting on [A | b], entirely in this
+                // thread's registers (every index is a compile-time constant after unrolling): the same element-wise expressions
+                // as the row-by-row algorithm, without the LDS round trips of a lane-per-row version.
                 const double lambda = K[10 + 16 + sh.lambdaLg10];   // exp(lambdaLg10 * log(10.)) tabulated by the host (|lambdaLg10| <= 16)
+                double a[6][7];
+#pragma unroll
                 for (int i = 0; i < 6; i++) {
-                    for (int k = 0; k < 6; k++) sh.Aug[i * 7 + k] = sh.JtJ[i * 6 + k];
-                    sh.Aug[i * 7 + i] *= 1. + lambda;
-                    sh.Aug[i * 7 + 6] = sh.JtErr[i];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) a[i][k] = sh.JtJ[i * 6 + k];
+                    a[i][i] *= 1. + lambda;
+                    a[i][6] = sh.JtErr[i];
                 }
-            }
-        }
-        __syncthreads();
-        if ((sh.state & 2) && tid < 64) {
-            // Gaussian elimination with partial pivoting on [A | b]: lane r owns row r (same per-element expressions as the
-            // row-by-row loop), back substitution on lane 0
-            const int r = tid;
-            bool ok = true;
-            for (int c = 0; c < 6; c++) {
-                int piv = c;
-                double best = fabs(sh.Aug[c * 7 + c]);
-                for (int q = c + 1; q < 6; q++) { const double v = fabs(sh.Aug[q * 7 + c]); if (v > best) { best = v; piv = q; } }
-                if (sh.Aug[piv * 7 + c] == 0.0) { ok = false; break; }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (piv != c && r < 7) { const double t = sh.Aug[c * 7 + r]; sh.Aug[c * 7 + r] = sh.Aug[piv * 7 + r]; sh.Aug[piv * 7 + r] = t; }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (r > c && r < 6) {
-                    const double f = sh.Aug[r * 7 + c] / sh.Aug[c * 7 + c];
-                    if (f != 0.0) {
-                        for (int k = c; k < 7; k++) sh.Aug[r * 7 + k] -= f * sh.Aug[c * 7 + k];
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    if (!ok) continue;
+                    int piv = c;
+                    double best = fabs(a[c][c]);
+#pragma unroll
+                    for (int q = c + 1; q < 6; q++) { const double v = fabs(a[q][c]); if (v > best) { best = v; piv = q; } }
+                    if (best == 0.0) { ok = false; continue; }
+#pragma unroll
+                    for (int q = c + 1; q < 6; q++) {
+                        if (piv == q) {
+#pragma unroll
+                            for (int k = 0; k < 7; k++) { const double t = a[c][k]; a[c][k] = a[q][k]; a[q][k] = t; }
+                        }
+                    }
+#pragma unroll
+                    for (int r = c + 1; r < 6; r++) {
+                        const double f = a[r][c] / a[c][c];
+                        if (f != 0.0) {
+#pragma unroll
+                            for (int k = c; k < 7; k++) a[r][k] -= f * a[c][k];
+                        }
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            if (r == 0) {
-                double bb[6];
+                double bb[6] = {0, 0, 0, 0, 0, 0};
                 if (ok) {
+#pragma unroll
                     for (int q = 5; q >= 0; q--) {
-                        double v = sh.Aug[q * 7 + 6];
-                        for (int k = q + 1; k < 6; k++) v -= sh.Aug[q * 7 + k] * bb[k];
-                        bb[q] = v / sh.Aug[q * 7 + q];
+                        double v = a[q][6];
+#pragma unroll
+                        for (int k = q + 1; k < 6; k++) v -= a[q][k] * bb[k];
+                        bb[q] = v / a[q][q];
                     }
-                } else for (int i = 0; i < 6; i++) bb[i] = 0;
+                }
+#pragma unroll
                 for (int i = 0; i < 6; i++) sh.param[i] = sh.prev[i] - bb[i];
-                sh.state &= 1;
             }
         }
         __syncthreads();
+        RSTAMP(12);
         if (sh.done) break;
+    }
+#undef RSTAMP
+    if (stamps && tid == 0) {   // diagnostic: [30] cycles before the LM loop, [31] cycles in it, [21] passes
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        stamps[30] += t_lm0 - t_start; stamps[31] += t_end - t_lm0; stamps[21] += n_pass;
     }
     if (tid < 6) rt_out[tid] = sh.param[tid];
     if (host_out) {   // the result block in mapped pinned host memory: no device-to-host copy afterwards
@@ -690,7 +715,7 @@ hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int
     hipLaunchKernelGGL(k_pnp_hyp, dim3(n_hyp), dim3(64), 0, s, d_obj, d_img, d_samples, d_K, d_models, m, thr, d_masks, d_counts, d_stamps); }
     ProfScope ps3(K_PNP_REFIT, s);
     hipLaunchKernelGGL(k_pnp_select_refit, dim3(1), dim3(RF_T), 0, s, d_obj, d_img, m, d_K, d_models, d_masks, d_counts, n_hyp,
-                       confidence, d_rt_out, d_inliers, d_info, host_out);
+                       confidence, d_rt_out, d_inliers, d_info, host_out, d_stamps);
     return hipGetLastError();
 }
 

@@ -16,3 +16,5 @@ st = np.zeros(32, np.uint64)
 ctx.lib.pmv_debug_ba_stamps(ctx.h, st.ctypes.data_as(C.POINTER(C.c_uint64)))
 d = [(int(st[22 + i]) - int(st0[22 + i])) / N for i in range(7)]
 print(" ".join("%s=%d" % (n, v) for n, v in zip(names, d)), "total", sum(d))
+print("refit: pre-LM cycles %d, LM cycles %d, LM passes %.1f per call" % ((int(st[30]) - int(st0[30])) / N, (int(st[31]) - int(st0[31])) / N, (int(st[21]) - int(st0[21])) / N))
+print("refit per pass: points %d, block_sum %d, decide+solve %d cycles" % tuple((int(st[k]) - int(st0[k])) / max(1, (int(st[21]) - int(st0[21]))) for k in (10, 11, 12)))
