@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--sequential", action="store_true", help="one host thread instead of front-end/back-end threads")
     ap.add_argument("--tri-threads", type=int, default=8, help="host threads evaluating the triangulator's five-point RANSAC hypotheses (single-sequence leg)")
+    ap.add_argument("--kitti-seq", default="07", help="sequence used when KITTI_ROOT points at a KITTI odometry tree (default: synthetic data)")
+    ap.add_argument("--poses-out", default="", help="write the estimated poses of the last step in KITTI format")
     ap.add_argument("--batch", type=int, default=8, help="extra leg: B independent sequences concurrently on the GPU (0 = skip)")
     args = ap.parse_args()
 
@@ -63,9 +65,20 @@ def main():
     seed = 1000 + 7 + rank   # "KITTI 07"-like on rank 0; every rank gets its own sequence
     ncpu = max(1, min(16, os.cpu_count() or 1))
     t0 = time.time()
-    frames, gt = pmv.synth_sequence(seed, 0, n, w, h, wl["fx"], wl["fy"], wl["cx"], wl["cy"], nthreads=ncpu)
+    data_kind = "synthetic"
+    kroot = os.environ.get("KITTI_ROOT", "")
+    if kroot and os.path.isdir(os.path.join(kroot, "sequences", args.kitti_seq)):
+        # real data: same config on KITTI odometry images, calibration and ground truth from the dataset files
+        kitti = importlib.import_module("practical-multi-view_amd.kitti")
+        frames, gt, Km = kitti.load_sequence(kroot, args.kitti_seq, n)
+        n, h, w = frames.shape
+        wl["n_frames"] = n
+        K = Km.reshape(9).copy()
+        data_kind = f"KITTI odometry sequence {args.kitti_seq} ({n} frames, {w}x{h}) from KITTI_ROOT"
+    else:
+        frames, gt = pmv.synth_sequence(seed, 0, n, w, h, wl["fx"], wl["fy"], wl["cx"], wl["cy"], nthreads=ncpu)
+        K = np.array([wl["fx"], 0, wl["cx"], 0, wl["fy"], wl["cy"], 0, 0, 1.0])
     t_gen = time.time() - t0
-    K = np.array([wl["fx"], 0, wl["cx"], 0, wl["fy"], wl["cy"], 0, 0, 1.0])
 
     ctx = pmv.Context(w, h, n_slots=n, max_tracks=4096, max_ba_cams=32, max_ba_points=8192, max_ba_obs=65536, device=local_rank)
     ctx.frames_stage(0, frames)   # inputs resident in HBM before the timed region
@@ -252,10 +265,10 @@ def main():
         "metric": "VO frames/sec on 1241x376 KITTI mono @400 tracks, bundle=5",
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8/int32 front-end, f64 back-end", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: synthetic KITTI-07-like sequence {w}x{h}, {n} frames, 400 tracks (tol 150), "
+        "dtype": "u8/int32 front-end, f64 back-end", "data": data_kind,
+        "config": {"workload": f"BASELINE configs[1]: {'synthetic KITTI-07-like' if data_kind == 'synthetic' else 'KITTI ' + args.kitti_seq} sequence {w}x{h}, {n} frames, 400 tracks (tol 150), "
                                f"bundle_size 5, 5 LM iterations, init_frames 5, GFTT+LK+EPnP-RANSAC+BA; one sequence per GPU",
-                   "frames_per_step": frames_per_step, "host_threads": 1 if args.sequential else 2 + (tri_threads - 1)},
+                   "frames_per_step": frames_per_step, "pipeline_seconds_last_step": round(st["seconds"], 4), "host_threads": 1 if args.sequential else 2 + (tri_threads - 1)},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "batched": batched,
@@ -272,6 +285,10 @@ def main():
     }
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
+    kitti_mod = importlib.import_module("practical-multi-view_amd.kitti")
+    out["reference_error_report"] = {k: round(v, 4) for k, v in kitti_mod.error_report(res.poses, gt, off).items()}   # OdometryPipeline.cpp:267-296
+    if args.poses_out:
+        kitti_mod.write_poses_kitti(args.poses_out, res.poses)
     print(json.dumps(out))
     ctx.close()
     if dist is not None:
