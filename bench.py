@@ -51,8 +51,17 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal aid (one-GPU box): PMV_BENCH_BACKEND=gloo runs the N-rank flow with CPU tensors, ranks share the visible GPUs
+        backend = os.environ.get("PMV_BENCH_BACKEND", "nccl")
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            tdev = "cuda"
+        else:
+            dist.init_process_group(backend=backend)
+            tdev = "cpu"
+        local_rank = dev_index
 
     pmv = importlib.import_module("practical-multi-view_amd")
     if not os.path.exists(pmv.lib_path()):
@@ -125,15 +134,15 @@ def main():
         res = step()
         kept.append(res)
         if dist is not None:   # final pose concatenation over RCCL/xGMI (latency-bound: <= 106 KB per rank)
-            buf = torch.zeros((n, 12), dtype=torch.float64, device="cuda")
-            buf[: res.poses.shape[0]] = torch.from_numpy(res.poses).cuda()
+            buf = torch.zeros((n, 12), dtype=torch.float64, device=tdev)
+            buf[: res.poses.shape[0]] = torch.from_numpy(res.poses).to(tdev)
             gathered = [torch.empty_like(buf) for _ in range(world)]
             dist.all_gather(gathered, buf)
     sync_all()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     for r_ in kept[:-1]:

@@ -93,6 +93,14 @@ int backend_create(pmv_ctx* c) {
     (void)hipHostFree(b->h_stage);
     CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes, hipHostMallocMapped));
     CKB(hipHostGetDevicePointer((void**)&b->d_h_stage, b->h_stage, 0));
+    {   // every buffer a kernel may touch exists (a missed allocation must fail here, not as a GPU fault later)
+        const void* must[] = {b->d_x, b->d_cand, b->d_scale, b->d_diag, b->d_D2, b->d_step, b->d_res, b->d_J, b->d_Einv, b->d_gp, b->d_Yd, b->d_Wd,
+                              b->d_S, b->d_rhs, b->d_Gpart, b->d_summary, b->d_stamps, b->d_bastate, b->d_bapart, b->d_counts, b->d_inliers,
+                              b->d_info, b->d_models, b->d_rt, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out, b->d_tri_in, b->d_tri_out,
+                              b->h_stage, b->d_h_stage};
+        for (const void* p : must)
+            if (!p) { set_err(c, "backend_create: internal error, a back-end buffer was not allocated"); return PMV_ERR_HIP; }
+    }
 #undef CKB
     return PMV_OK;
 }

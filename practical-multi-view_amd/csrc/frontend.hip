@@ -101,14 +101,14 @@ __device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0
 }
 
 __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS,
-                                           PyrLayout L, const float* __restrict__ prev_xy, int n, LKParams P,
+                                           PyrLayout L, const float* __restrict__ prev_xy, const int* __restrict__ order, int n, LKParams P,
                                            float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
                                            float* __restrict__ out_err) {
     __shared__ __attribute__((aligned(16))) uint8_t sI[35 * SI_STRIDE];
     __shared__ __attribute__((aligned(16))) short2 sD[33 * SD_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t sJ[64 * SJ_STRIDE];
-    const int t = blockIdx.x;
-    if (t >= n) return;
+    const int t = order[blockIdx.x];   // block -> track (XCD-aware order built by the host; -1 = no track)
+    if (t < 0 || t >= n) return;
     const int lane = threadIdx.x;
     const int r = lane >> 1, c0 = (lane & 1) * 16;
     const float px0 = prev_xy[2 * t], py0 = prev_xy[2 * t + 1];
@@ -275,10 +275,11 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
 }
 
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
-                     const float* d_prev_xy, int n, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err) {
+                     const float* d_prev_xy, const int* d_order, int n_blocks, int n, const LKParams& P, float* d_out_xy,
+                     uint8_t* d_status, float* d_err) {
     if (n <= 0) return hipSuccess;
     ProfScope ps(K_LK, s);
-    hipLaunchKernelGGL(k_lk, dim3(n), dim3(64), 0, s, prev_slot, next_slot, L, d_prev_xy, n, P, d_out_xy, d_status, d_err);
+    hipLaunchKernelGGL(k_lk, dim3(n_blocks), dim3(64), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
     return hipGetLastError();
 }
 

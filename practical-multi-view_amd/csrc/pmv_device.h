@@ -80,7 +80,8 @@ struct LKParams {
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n);
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int level_dst, int first_slot, int n);
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
-                     const float* d_prev_xy, int n, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err);
+                     const float* d_prev_xy, const int* d_order, int n_blocks, int n, const LKParams& P, float* d_out_xy,
+                     uint8_t* d_status, float* d_err);
 
 // GFTT: eig maps (n_cells * 255*255 floats), cell max (n_cells uint32 ordered keys), outputs
 hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
