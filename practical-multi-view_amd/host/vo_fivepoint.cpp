@@ -538,6 +538,8 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
         pool->begin();
     }
     HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[4]);
+    for (auto& p : src.map) { p.first->map_slot = &p.second; p.first->map_owner = &src.map; }     // src.map[..] / next.map[..] below without hashing
+    for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }
     for (auto& p : src.feat_corr) {
         if (p.first.expired() || p.second.expired()) continue;
         std::shared_ptr<Feature> fst = p.first.lock();
@@ -583,8 +585,8 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
             f3d->transform(tracker->R[j], tracker->t[j]);
             tracker->feats3d.push_back(f3d);
             f3d->self = std::prev(tracker->feats3d.end());
-            next.map[p2_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
-            src.map[p1_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
+            if (p2_ptr[i]->map_owner == (const void*)&next.map) *p2_ptr[i]->map_slot = std::weak_ptr<Feature3D>(f3d); else next.map[p2_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
+            if (p1_ptr[i]->map_owner == (const void*)&src.map) *p1_ptr[i]->map_slot = std::weak_ptr<Feature3D>(f3d); else src.map[p1_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
         }
     }
 }

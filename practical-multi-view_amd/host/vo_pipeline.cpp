@@ -102,6 +102,12 @@ fmap LucasKanadeFMBase::matchFeatures(Frame& src, Frame& next) {
 }
 
 // ---- OpenCVEPnPSolver.cpp:4-50 ---------------------------------------------------------------------------------
+// front-end: remember, in the key object of every feat_corr entry, where the entry lives (see Feature::corr_slot)
+static void index_feat_corr(Frame& fr) {
+    for (auto& p : fr.feat_corr)
+        if (std::shared_ptr<Feature> k = p.first.lock()) { k->corr_slot = &p.second; k->corr_owner = &fr.feat_corr; }
+}
+
 void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
     const int j = src.frame;
     std::vector<float> obj_points, img_points;
@@ -110,12 +116,18 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
     std::vector<std::weak_ptr<Feature3D>> local_feats3d;
     HostProfScope* hps = new HostProfScope(tracker->stats.hp.t[0]);
     obj_points.reserve(3 * src.map.size()); img_points.reserve(2 * src.map.size()); local_feats3d.reserve(src.map.size());
+    for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }   // next.map[f] below without hashing
     for (auto& p : src.map) {
         std::shared_ptr<Feature3D> f3d = p.second.lock();    // (expired() + lock() in the reference: one atomic round trip here)
         if (!f3d) continue;
-        std::shared_ptr<Feature> f = src.feat_corr[p.first].lock();   // operator[] inserts empty entries (quirk Q10); looked up once
+        // src.feat_corr[p.first]: the entry found by coordinate equality. If this very object is the entry's key the front-end
+        // left its address in corr_slot; otherwise (same-pixel twin, or no correspondence) look it up as the reference does —
+        // operator[] then inserts the empty entry of quirk Q10.
+        std::weak_ptr<Feature>* cs = p.first->corr_owner == (const void*)&src.feat_corr ? p.first->corr_slot : nullptr;
+        std::shared_ptr<Feature> f = cs ? cs->lock() : src.feat_corr[p.first].lock();
         if (!f) continue;
-        next.map[f] = std::weak_ptr<Feature3D>(f3d);
+        if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
+        else next.map[f] = std::weak_ptr<Feature3D>(f3d);
         f3d->transformInv(tracker->R[j], tracker->t[j]);
         float px = f3d->x, py = f3d->y, pz = f3d->z;
         pz *= -1;
@@ -294,6 +306,7 @@ void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
     stats.t_lk += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
     stats.lk_calls++; stats.lk_points += (long)frames[frame.frame - 1]->map.size();
     frames[frame.frame - 1]->feat_corr = feat_corr;
+    index_feat_corr(*frames[frame.frame - 1]);
     if ((int)feat_corr.size() < cfg.tracked_features_tol) {
         std::vector<GridSection> roi = getGridROI(*(frames[frames.size() - 1]));   // cells of the PREVIOUS frame (quirk Q3)
         const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
@@ -421,6 +434,7 @@ void OdometryPipeline::run_threaded() {
         stats.t_lk += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
         stats.lk_calls++; stats.lk_points += (long)prev->map.size();
         prev->feat_corr = feat_corr;
+        index_feat_corr(*prev);
         if ((int)feat_corr.size() < cfg.tracked_features_tol) {
             std::vector<GridSection> roi = getGridROI(*prev);
             const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());

@@ -46,6 +46,7 @@ inline Vec3 operator*(double s, const Vec3& a) { return Vec3{{s * a.v[0], s * a.
 // std::hash<std::string>{}(std::to_string(v)) memoised for the coordinate range features can take
 size_t coord_hash(int v);
 
+class Feature3D;
 // Feature.h:10-86
 class Feature {
 public:
@@ -56,6 +57,13 @@ public:
     bool tracked = true;
     double score = 0;
     double displacement = 0;
+    // Host-side shortcuts (not in the reference, no effect on any result): where this feature's entries live in its frame's
+    // containers, so the back-end adapters do not hash/compare weak_ptr keys (several atomic reference-count round trips per
+    // lookup). Unordered-map nodes are address-stable; a null slot means "look it up as the reference does".
+    std::weak_ptr<Feature3D>* map_slot = nullptr;    // &frame.map[this] (set by the adapter that is about to use it)
+    std::weak_ptr<Feature>* corr_slot = nullptr;     // &frame.feat_corr[this] when THIS object is the entry's key (set by the front-end)
+    const void* map_owner = nullptr;                 // the container each slot points into: a slot is only used for that container
+    const void* corr_owner = nullptr;
 
     Feature(int column_, int row_) : row(row_), column(column_) {}
     Feature() { tracked = false; }
