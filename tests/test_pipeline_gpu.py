@@ -93,3 +93,12 @@ def test_config3_like_800_tracks_bundle10(pmv, gpu_ctx_factory):
 def test_shitomasi_extractor_pipeline(pmv, gpu_ctx_factory):
     g, o, _ = _run_both(pmv, gpu_ctx_factory, K07, 24, 1003, extractor=1)
     _compare(g, o, 1e-6)
+
+
+def test_config4_like_1080p_2000_tracks_bundle20(pmv, gpu_ctx_factory):
+    """BASELINE configs[3] shape (1920x1080, 2000 tracks, tol 750, bundle 20 -> 8x5 grid, 5 pyramid levels, BA every 12 frames with
+    up to 20 cameras = a 120x120 reduced system): short run, same bars as the other configs."""
+    cfg = dict(w=1920, h=1080, fx=1000.0, fy=1000.0, cx=960.0, cy=540.0)
+    g, o, _ = _run_both(pmv, gpu_ctx_factory, cfg, 40, 1010, min_tracked=2000, tol=750, bundle_size=20)
+    _compare(g, o, 1e-6)
+    assert g.stats["ba_calls"] >= 2 and g.stats["lk_points"] > 20 * 1500
