@@ -127,3 +127,42 @@ def test_triangulate_candidates_bit_exact(gpu_ctx_factory, seed, n):
     ok = mask[0].astype(bool)
     if ok.sum() > 10:
         assert np.median(np.linalg.norm(X[ok] - P["X"][ok], axis=1) / P["X"][ok, 2]) < 0.05
+
+
+def test_ba_duplicate_point_camera_observations(gpu_ctx_factory):
+    """The reference can observe one landmark twice in the same frame (two same-pixel features): both residual blocks
+    enter the problem. The point kernel folds such duplicates into the first entry of the (point, camera) group."""
+    P = scenes.ba_problem(13, nc=5, npts=250)
+    rng = np.random.default_rng(5)
+    dup = rng.choice(len(P["obs"]), 60, replace=False)
+    obs = np.vstack([P["obs"], P["obs"][dup] + rng.normal(0, 0.4, (60, 2))])
+    ci = np.concatenate([P["cam_idx"], P["cam_idx"][dup]]).astype(np.int32)
+    pi = np.concatenate([P["pt_idx"], P["pt_idx"][dup]]).astype(np.int32)
+    ctx = _ctx(gpu_ctx_factory)
+    cams, pts, s = ctx.ba_solve(P["cams"], P["pts"], obs, ci, pi, scenes.K, 1.0, 5)
+    rc, rp, rs = ob.ba_solve(P["cams"], P["pts"], obs, ci, pi, scenes.K, 1.0, 5)
+    np.testing.assert_allclose(s.initial_cost, rs["initial_cost"], rtol=1e-12)
+    assert s.iterations == rs["iterations"] and s.successful_steps == rs["successful_steps"]
+    np.testing.assert_allclose(s.final_cost, rs["final_cost"], rtol=1e-8)
+    np.testing.assert_allclose(cams, rc, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pts, rp, rtol=1e-6, atol=1e-6)
+
+
+def test_backend_argument_errors(pmv, gpu_ctx_factory):
+    ctx = gpu_ctx_factory(64, 64, n_slots=1, max_tracks=128, max_ba_cams=4, max_ba_points=64, max_ba_obs=256)
+    P = scenes.ba_problem(2, nc=3, npts=40)
+    with pytest.raises(pmv.PmvError) as e:     # LM iteration count must be 1..512
+        ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 0)
+    assert e.value.code == -2
+    with pytest.raises(pmv.PmvError) as e:     # more cameras than the context was created for
+        Q = scenes.ba_problem(2, nc=5, npts=40)
+        ctx.ba_solve(Q["cams"], Q["pts"], Q["obs"], Q["cam_idx"], Q["pt_idx"], scenes.K)
+    assert e.value.code == -3
+    T = scenes.two_view_problem(1, n=200)
+    with pytest.raises(pmv.PmvError) as e:     # more correspondences than max_tracks
+        ctx.triangulate_candidates(T["q1"], T["q2"], T["P1x4"], T["mask"])
+    assert e.value.code == -3
+    bad = P["cam_idx"].copy(); bad[3] = 7
+    with pytest.raises(pmv.PmvError) as e:     # index out of range is caught on the host, never reaches a kernel
+        ctx.ba_solve(P["cams"], P["pts"], P["obs"], bad, P["pt_idx"], scenes.K)
+    assert e.value.code == -2
