@@ -166,3 +166,26 @@ def test_backend_argument_errors(pmv, gpu_ctx_factory):
     with pytest.raises(pmv.PmvError) as e:     # index out of range is caught on the host, never reaches a kernel
         ctx.ba_solve(P["cams"], P["pts"], P["obs"], bad, P["pt_idx"], scenes.K)
     assert e.value.code == -2
+
+
+def test_ba_single_workgroup_variant_agrees(gpu_ctx_factory):
+    """PMV_BA_MODE=single selects the one-workgroup persistent LM kernel (k_ba_lm, the first implementation, kept as an A/B
+    reference); the mode is read once per process, so it runs in a child process. Same problem, same answer within the BA bar."""
+    import json, os, subprocess, sys
+    P = scenes.ba_problem(17, nc=5, npts=300)
+    ctx = _ctx(gpu_ctx_factory)
+    cams, pts, s = ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 5)
+    code = ("import sys, json, importlib, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); import scenes; "
+            "pmv = importlib.import_module('practical-multi-view_amd'); ctx = pmv.Context(64, 64, n_slots=1); "
+            "P = scenes.ba_problem(17, nc=5, npts=300); "
+            "c, p, s = ctx.ba_solve(P['cams'], P['pts'], P['obs'], P['cam_idx'], P['pt_idx'], scenes.K, 1.0, 5); "
+            "print(json.dumps(dict(cams=c.tolist(), pts=p.tolist(), cost=s.final_cost, it=s.iterations, ok=s.successful_steps)))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PMV_BA_MODE="single"), capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["it"] == s.iterations and r["ok"] == s.successful_steps
+    np.testing.assert_allclose(r["cost"], s.final_cost, rtol=1e-8)
+    np.testing.assert_allclose(np.array(r["cams"]), cams, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(np.array(r["pts"]), pts, rtol=1e-6, atol=1e-6)
