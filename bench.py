@@ -63,6 +63,9 @@ def main():
             tdev = "cpu"
         local_rank = dev_index
 
+    # The batched leg drives 2 HIP streams per sequence; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4),
+    # and streams that share a queue serialise. Measured with 8 sequences: 4 queues 5100 frames/s, 8 -> 6400, 16 -> 7200.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     pmv = importlib.import_module("practical-multi-view_amd")
     if not os.path.exists(pmv.lib_path()):
         importlib.import_module("practical-multi-view_amd.build").build_all()
