@@ -29,8 +29,8 @@ WORKLOAD = dict(w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=WORKLOAD["n_frames"], help="frames per sequence (default: metric config)")
     ap.add_argument("--cpu-frames", type=int, default=150, help="bounded sample for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
