@@ -9,6 +9,7 @@
 //   Schur complement  S -= Yd^T Wd,  rhs -= Yd^T g   as ONE dense contraction on FP64 MFMA (v_mfma_f64_16x16x4_f64)  ->
 //   Cholesky of the reduced camera matrix -> back-substitution -> model cost change -> candidate cost -> accept/reject.
 #include "pmv_ctx.h"
+#include <algorithm>
 #include "backend.h"
 #include "pmv_prof.h"
 #include <float.h>
@@ -842,8 +843,14 @@ __device__ inline void bam_eval0_role(const BAArgs& A, BAGState* __restrict__ st
     if (tid == 0) part_cost[bid] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(BM_T) void k_bam_eval0(BAArgs A, BAGState* st_out, int* chol_flags, double* part_cost) {
-    bam_eval0_role(A, st_out, chol_flags, part_cost, blockIdx.x, gridDim.x);
+// blocks [0, eval_blocks): E0; the remaining blocks clear Yt | [Wt | g] (adjacent; columns of cameras that do not see a point are
+// never written by the point kernel) — the clear rides along instead of being a launch of its own
+__global__ __launch_bounds__(BM_T) void k_bam_eval0(BAArgs A, BAGState* st_out, int* chol_flags, double* part_cost, int eval_blocks) {
+    if ((int)blockIdx.x < eval_blocks) { bam_eval0_role(A, st_out, chol_flags, part_cost, blockIdx.x, eval_blocks); return; }
+    const size_t n2 = (size_t)A.krows * A.ldw;   // doubles in Yt + Wt = 2 * n2, a multiple of 2
+    double2* z = (double2*)A.Yd;
+    const int zb = blockIdx.x - eval_blocks, nzb = gridDim.x - eval_blocks;
+    for (size_t i = (size_t)zb * BM_T + threadIdx.x; i < n2; i += (size_t)nzb * BM_T) z[i] = double2{0.0, 0.0};
 }
 
 // C role: one block (4 wavefronts) per camera: U_c (6x6) and rhs_c on FP64 MFMA; in the first iteration also the Jacobi
@@ -1515,13 +1522,11 @@ hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    // Yt and [Wt | g] are adjacent: one clear (columns of cameras that do not see a point are never written)
-    hipError_t e = hipMemsetAsync(A.Yd, 0, 2 * (size_t)A.krows * A.ldw * sizeof(double), s);
-    if (e != hipSuccess) return e;
     ProfScope ps(K_BA_LM, s);
     const int tiles = A.tiles_r * A.tiles_c;
-    // launches: E0, then per iteration C|P (with the decision on the previous step) -> G -> S -> B, then F
-    hipLaunchKernelGGL(k_bam_eval0, dim3(nbo), dim3(BM_T), 0, s, A, st2[1], chol_flags, part_cost);
+    // launches: E0 (+ the clear of Yt | Wt), then per iteration C|P (with the decision on the previous step) -> G -> S -> B, then F
+    const int clear_blocks = (int)std::min<size_t>(64, ((size_t)A.krows * A.ldw + 4 * BM_T - 1) / (4 * BM_T));
+    hipLaunchKernelGGL(k_bam_eval0, dim3(nbo + clear_blocks), dim3(BM_T), 0, s, A, st2[1], chol_flags, part_cost, nbo);
     for (int it = 0; it < A.max_iterations; it++) {
         BAGState* sin = st2[it & 1];
         BAGState* sc = st2[(it + 1) & 1];   // the state of this iteration

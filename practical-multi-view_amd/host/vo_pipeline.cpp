@@ -105,7 +105,7 @@ fmap LucasKanadeFMBase::matchFeatures(Frame& src, Frame& next) {
 // front-end: remember, in the key object of every feat_corr entry, where the entry lives (see Feature::corr_slot)
 static void index_feat_corr(Frame& fr) {
     for (auto& p : fr.feat_corr)
-        if (std::shared_ptr<Feature> k = p.first.lock()) { k->corr_slot = &p.second; k->corr_owner = &fr.feat_corr; }
+        if (std::shared_ptr<Feature> k = p.first.lock()) { k->corr_slot = &p.second; k->corr_owner = &fr.feat_corr; k->corr_feat = p.second.lock().get(); }
 }
 
 void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
@@ -123,11 +123,19 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
         // src.feat_corr[p.first]: the entry found by coordinate equality. If this very object is the entry's key the front-end
         // left its address in corr_slot; otherwise (same-pixel twin, or no correspondence) look it up as the reference does —
         // operator[] then inserts the empty entry of quirk Q10.
-        std::weak_ptr<Feature>* cs = p.first->corr_owner == (const void*)&src.feat_corr ? p.first->corr_slot : nullptr;
-        std::shared_ptr<Feature> f = cs ? cs->lock() : src.feat_corr[p.first].lock();
-        if (!f) continue;
-        if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
-        else next.map[f] = std::weak_ptr<Feature3D>(f3d);
+        Feature* f;
+        if (p.first->corr_owner == (const void*)&src.feat_corr) {
+            f = p.first->corr_feat;                       // no reference-count traffic on the (front-end-created) feature
+            if (!f) continue;
+            if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
+            else next.map[p.first->corr_slot->lock()] = std::weak_ptr<Feature3D>(f3d);
+        } else {
+            std::shared_ptr<Feature> fs = src.feat_corr[p.first].lock();
+            if (!fs) continue;
+            f = fs.get();
+            if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
+            else next.map[fs] = std::weak_ptr<Feature3D>(f3d);
+        }
         f3d->transformInv(tracker->R[j], tracker->t[j]);
         float px = f3d->x, py = f3d->y, pz = f3d->z;
         pz *= -1;

@@ -62,6 +62,7 @@ public:
     // lookup). Unordered-map nodes are address-stable; a null slot means "look it up as the reference does".
     std::weak_ptr<Feature3D>* map_slot = nullptr;    // &frame.map[this] (set by the adapter that is about to use it)
     std::weak_ptr<Feature>* corr_slot = nullptr;     // &frame.feat_corr[this] when THIS object is the entry's key (set by the front-end)
+    Feature* corr_feat = nullptr;                    // the feature *corr_slot refers to (frames, and with them their features, live for the whole run)
     const void* map_owner = nullptr;                 // the container each slot points into: a slot is only used for that container
     const void* corr_owner = nullptr;
 
