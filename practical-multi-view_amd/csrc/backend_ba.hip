@@ -908,29 +908,10 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
     const int tid = threadIdx.x;
     const int p0 = pb * BM_PB, p1 = min(A.np, p0 + BM_PB);
     const int p = p0 + tid;
+    double* sSp = sEi + BM_PB * 9;   // [BM_PB][3] point scales (first iteration)
     double gmax_p = 0;
     if (tid < BM_PB && p < p1) {
         const int e0 = A.pobs_start[p], e1 = A.pobs_start[p + 1];
-        if (st.first) {   // Jacobi scaling: columns of the point from its own rows, columns of the cameras from the C kernel
-            double acc[3] = {0, 0, 0};
-            for (int e = e0; e < e1; e++) {
-                const double* Jp = Jb + (size_t)A.pobs_list[e] * 18 + 12;
-#pragma unroll
-                for (int k = 0; k < 3; k++) acc[k] += Jp[k] * Jp[k] + Jp[3 + k] * Jp[3 + k];
-            }
-            double sp[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { sp[k] = 1.0 / (1.0 + sqrt(acc[k])); A.scale[m + 3 * p + k] = sp[k]; }
-            for (int e = e0; e < e1; e++) {
-                const int i = A.pobs_list[e];
-                const double* sc = A.scale + 6 * A.cam_idx[i];
-                double* Jo = Jb + (size_t)i * 18;
-#pragma unroll
-                for (int k = 0; k < 12; k++) Jo[k] *= sc[k % 6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) Jo[12 + k] *= sp[k % 3];
-            }
-        }
         double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
         for (int eb = e0; eb < e1; eb += BM_OB) {   // index loads, then value loads, then arithmetic: independent loads in flight
             int oi[BM_OB];
@@ -960,6 +941,19 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
                         gv[a] += jp[u][a] * rr[u][0] + jp[u][3 + a] * rr[u][1];
                     }
                 }
+            }
+        }
+        if (st.first) {
+            // Jacobi scaling of the point's columns: their squared norms are the diagonal of the unscaled E; E and g of the
+            // scaled problem follow by scaling (the Jacobian rows themselves are rescaled by the per-observation pass below)
+            double sp[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { sp[k] = 1.0 / (1.0 + sqrt(E[k * 3 + k])); A.scale[m + 3 * p + k] = sp[k]; sSp[tid * 3 + k] = sp[k]; }
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+#pragma unroll
+                for (int b = 0; b < 3; b++) E[a * 3 + b] = E[a * 3 + b] * sp[a] * sp[b];
+                gv[a] = gv[a] * sp[a];
             }
         }
         const double radius = st.radius;
@@ -1007,9 +1001,22 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) gmax_p = fmax(gmax_p, __shfl_xor(gmax_p, o, 64));
     if (tid == 0) part_gmax[pb] = gmax_p;   // the points of the block live in wavefront 0
-    __syncthreads();                        // E^-1 in LDS, scaled Jacobian rows (first iteration) in global memory
-    // ---- phase 2: K-columns of cameras that do not see a point stay zero (Yt / Wt are cleared once per solve)
+    __syncthreads();                        // E^-1 (and, first iteration, the point scales) in LDS
     const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
+    if (st.first) {   // block-uniform: one thread per observation rescales its Jacobian row in place (cameras: scales of the C kernel)
+        for (int e = eb0 + tid; e < eb1; e += BM_T) {
+            const int i = A.pobs_list[e];
+            const double* sc = A.scale + 6 * A.cam_idx[i];
+            const double* sp = sSp + (A.pt_idx[i] - p0) * 3;
+            double* Jo = Jb + (size_t)i * 18;
+#pragma unroll
+            for (int k = 0; k < 12; k++) Jo[k] *= sc[k % 6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Jo[12 + k] *= sp[k % 3];
+        }
+        __syncthreads();   // rows of duplicate observations are read by other threads below
+    }
+    // ---- phase 2: K-columns of cameras that do not see a point stay zero (Yt / Wt are cleared once per solve)
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
         const int flag = A.odup[e];
         if (flag == 2) continue;   // a later observation of the same (point, camera): folded into the first one
@@ -1066,7 +1073,7 @@ __device__ inline void bam_campoint_role(const BAArgs& A, const BAGState* __rest
                                          double* Ublk, double* rhsblk, double* part_gmax, int bid, double* sred /* [BM_WORK] */) {
     __shared__ BAGState ss;
     __shared__ double ssc[8];
-    static_assert(BM_PB * 9 <= BM_WORK, "LDS");
+    static_assert(BM_PB * 12 <= BM_WORK, "LDS");
     if (threadIdx.x == 0) {
         ss = *st_in;
         if (decide) {
