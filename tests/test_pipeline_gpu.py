@@ -102,3 +102,24 @@ def test_config4_like_1080p_2000_tracks_bundle20(pmv, gpu_ctx_factory):
     g, o, _ = _run_both(pmv, gpu_ctx_factory, cfg, 40, 1010, min_tracked=2000, tol=750, bundle_size=20)
     _compare(g, o, 1e-6)
     assert g.stats["ba_calls"] >= 2 and g.stats["lk_points"] > 20 * 1500
+
+
+def test_metric_config_full_sequence(pmv, gpu_ctx_factory):
+    """BASELINE configs[1] at full length (1241x376, 1101 frames, 400 tracks, bundle 5): every 2-D feature of every frame bit-exact,
+    front-end call statistics exact, trajectories within the drift bar (the oracle needs ~15 s of CPU for this)."""
+    cfg = K00
+    n = 1101
+    frames, poses = pmv.synth_sequence(1007, 0, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16)
+    K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096, max_ba_cams=32, max_ba_points=8192, max_ba_obs=65536)
+    ctx.frames_stage(0, frames)
+    g = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1, n_threads=8)
+    o = ob.run_pipeline(frames, K, poses, threaded=1, n_threads=15)
+    assert len(g.features) == len(o.features) == n
+    for k, (a, b) in enumerate(zip(g.features, o.features)):
+        assert np.array_equal(a[:, :2], b[:, :2]), f"feature coordinates differ in frame {k}"
+    for key in ("lk_calls", "lk_points", "detect_calls", "init_offset"):
+        assert g.stats[key] == o.stats[key], key
+    travelled = np.linalg.norm(o.poses[:, 9:12], axis=1)
+    dt = np.linalg.norm(g.poses[:, 9:12] - o.poses[:, 9:12], axis=1)
+    assert (dt <= 0.02 * travelled + 0.05).all(), f"trajectories drift apart: {dt.max()}"
