@@ -188,10 +188,32 @@ __global__ __launch_bounds__(256) void k_ba_residuals(const double* __restrict__
 }
 
 // ---- deterministic block reductions -----------------------------------------------------------------------------------
+// Wavefront all-reduce of doubles on DPP row operations (a ds_bpermute shuffle of an f64 costs ~160 clk per step, a DPP move
+// ~10): quad butterflies, row_half_mirror, row_mirror give every lane its 16-lane row sum; the four row sums are fetched with
+// lane reads and added in a fixed order. Every lane receives the same bits.
+__device__ inline double dpp_f64(double v, const int ctrl_sel) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_sel) {   // the DPP control must be an immediate
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, false); break;
+    }
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double readlane_f64_c(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ inline double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f64(v, 0);   // quad_perm [1,0,3,2]
+    v += dpp_f64(v, 1);   // quad_perm [2,3,0,1]
+    v += dpp_f64(v, 2);   // row_half_mirror
+    v += dpp_f64(v, 3);   // row_mirror
+    return (readlane_f64_c(v, 0) + readlane_f64_c(v, 16)) + (readlane_f64_c(v, 32) + readlane_f64_c(v, 48));
+}
+__device__ inline double wave_max_f64(double v) {
+    v = fmax(v, dpp_f64(v, 0)); v = fmax(v, dpp_f64(v, 1)); v = fmax(v, dpp_f64(v, 2)); v = fmax(v, dpp_f64(v, 3));
+    return fmax(fmax(readlane_f64_c(v, 0), readlane_f64_c(v, 16)), fmax(readlane_f64_c(v, 32), readlane_f64_c(v, 48)));
 }
 // every thread gets the sum; red: BA_NW doubles of LDS
 __device__ inline double block_sum(double v, double* red) {
@@ -205,8 +227,7 @@ __device__ inline double block_sum(double v, double* red) {
     return s;
 }
 __device__ inline double block_max(double v, double* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    v = wave_max_f64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -998,8 +1019,7 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
 #pragma unroll
         for (int k = 0; k < 3; k++) { A.gp[(size_t)p * 3 + k] = gv[k]; A.Wd[(size_t)m * krows + 3 * p + k] = gv[k]; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) gmax_p = fmax(gmax_p, __shfl_xor(gmax_p, o, 64));
+    gmax_p = wave_max_f64(gmax_p);
     if (tid == 0) part_gmax[pb] = gmax_p;   // the points of the block live in wavefront 0
     __syncthreads();                        // E^-1 (and, first iteration, the point scales) in LDS
     const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
@@ -1172,8 +1192,7 @@ __device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const int* 
         for (int i = tid; i < nbp; i += BM_T) g = fmax(g, part_gmax[i]);
         for (int i = tid; i < nbo; i += BM_T) cs += part_cost[i];
         xn = wave_sum_f64(xn); cs = wave_sum_f64(cs);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o, 64));
+        g = wave_max_f64(g);
         if (lane == 0) { red[wid] = xn; red[BM_NW + wid] = cs; red[2 * BM_NW + wid] = g; }
         __syncthreads();
         if (tid == 0) {
