@@ -1406,6 +1406,8 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
     __shared__ double sP[BM_PB * 6];   // per point of the block: step (3), candidate point (3)
     if (st->done || !st->step_valid) return;
     const int tid = threadIdx.x;
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#define BSTAMP(k) do { if (A.stamps && bid == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); A.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
     const int nc = A.nc, m = 6 * nc, n = m + 3 * A.np;
     const int cur = st->cur;
     const double* x = A.x + (size_t)cur * n;
@@ -1429,6 +1431,7 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
         for (int a = 0; a < 3; a++) tmp3[(size_t)e * 3 + a] = Jr[12 + a] * jy0 + Jr[15 + a] * jy1;
     }
     __syncthreads();
+    BSTAMP(10);
     const int p = p0 + tid;
     if (tid < BM_PB && p < p1) {
         double t3[3] = {A.gp[(size_t)p * 3], A.gp[(size_t)p * 3 + 1], A.gp[(size_t)p * 3 + 2]};
@@ -1449,6 +1452,7 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
         }
     }
     __syncthreads();
+    BSTAMP(11);
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
         const int i = A.pobs_list[e];
         const int c = A.cam_idx[i], pl = A.pt_idx[i] - p0;
@@ -1490,6 +1494,7 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
         }
         cc += 0.5 * rho0;
     }
+    BSTAMP(12);
     if (bid == 0) {   // camera part of the candidate and of the step norm
         for (int i = tid; i < m; i += BM_T) {
             const double d = A.step[i] * A.scale[i];
@@ -1505,6 +1510,8 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
         part4[bid * 4 + 1] = (red[BM_NW] + red[BM_NW + 1]) + (red[BM_NW + 2] + red[BM_NW + 3]);
         part4[bid * 4 + 2] = (red[2 * BM_NW] + red[2 * BM_NW + 1]) + (red[2 * BM_NW + 2] + red[2 * BM_NW + 3]);
     }
+    BSTAMP(13);
+#undef BSTAMP
 }
 
 __global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* st, const double* candrot, double* tmp3, double* part4) {

@@ -14,4 +14,6 @@ for nc, npts in ((5, 400), (10, 1000), (20, 1500)):
     st = np.zeros(32, np.uint64)
     ctx.lib.pmv_debug_ba_stamps(ctx.h, st.ctypes.data_as(C.POINTER(C.c_uint64)))
     d = [(int(st[16 + i]) - int(st0[16 + i])) / max(1, s.iterations) for i in range(5)]
+    db = [(int(st[10 + i]) - int(st0[10 + i])) / max(1, s.iterations) for i in range(4)]
+    print("   backsub kernel (block 0): phaseA=%d phaseB=%d phaseC=%d reduce=%d" % tuple(db))
     print("nc", nc, "iterations", s.iterations, " ".join("%s=%d" % (n, v) for n, v in zip(names, d)), "cycles/iteration (100 MHz counter?)")
