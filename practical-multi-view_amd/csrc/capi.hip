@@ -77,8 +77,14 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     CK(hipMalloc(&c->d_prev_xy, nt * 12 + 64));   // track coordinates followed by the block -> track order
     CK(hipMalloc(&c->d_out_xy, nt * 8));
     CK(hipMalloc(&c->d_status, nt)); CK(hipMalloc(&c->d_err, nt * 4));
-    CK(hipHostMalloc(&c->h_prev_xy, nt * 12 + 64)); CK(hipHostMalloc(&c->h_out_xy, nt * 8));
-    CK(hipHostMalloc(&c->h_status, nt)); CK(hipHostMalloc(&c->h_err, nt * 4));
+    CK(hipHostMalloc(&c->h_prev_xy, nt * 12 + 64));
+    // LK results: 13 bytes per track, written by the kernel through the device aliases of these mapped pinned buffers (no D2H copies)
+    CK(hipHostMalloc(&c->h_out_xy, nt * 8, hipHostMallocMapped));
+    CK(hipHostMalloc(&c->h_status, nt, hipHostMallocMapped));
+    CK(hipHostMalloc(&c->h_err, nt * 4, hipHostMallocMapped));
+    CK(hipHostGetDevicePointer((void**)&c->dm_out_xy, c->h_out_xy, 0));
+    CK(hipHostGetDevicePointer((void**)&c->dm_status, c->h_status, 0));
+    CK(hipHostGetDevicePointer((void**)&c->dm_err, c->h_err, 0));
     CK(hipMalloc(&c->d_cells, MAX_CELLS * 16));
     CK(hipMalloc(&c->d_eig, (size_t)MAX_CELLS * CELL_PIX * sizeof(double)));   // shared by GFTT (f32) and ShiTomasi (f64)
     CK(hipMalloc(&c->d_cellmax, MAX_CELLS * 8));
@@ -93,7 +99,7 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     int rc = backend_create(c);
     if (rc != PMV_OK) { snprintf(g_create_err, sizeof(g_create_err), "%s", c->err); pmv_ctx_destroy(c); return rc; }
     {   // every buffer a kernel may touch exists (a missed allocation must fail here, not as a GPU fault later)
-        const void* must[] = {c->d_slots, c->d_prev_xy, c->d_out_xy, c->d_status, c->d_err, c->h_prev_xy, c->h_out_xy, c->h_status, c->h_err,
+        const void* must[] = {c->dm_out_xy, c->dm_status, c->dm_err, c->d_slots, c->d_prev_xy, c->d_out_xy, c->d_status, c->d_err, c->h_prev_xy, c->h_out_xy, c->h_status, c->h_err,
                               c->d_cells, c->d_eig, c->d_cellmax, c->d_det_xy, c->d_det_score, c->d_det_count, c->d_flags, c->h_det_xy,
                               c->h_det_score, c->h_det_count};
         for (const void* p : must)
@@ -248,11 +254,8 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     LKParams P;
     P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f;
     CKC(launch_lk(ctx->s_front, ctx->d_slots + (size_t)prev_slot * L.slot_bytes, ctx->d_slots + (size_t)next_slot * L.slot_bytes,
-                  L, ctx->d_prev_xy, (const int*)(ctx->d_prev_xy + (size_t)2 * n), nb, n, P, ctx->d_out_xy, ctx->d_status, ctx->d_err));
-    CKC(hipMemcpyAsync(ctx->h_out_xy, ctx->d_out_xy, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->s_front));
-    CKC(hipMemcpyAsync(ctx->h_status, ctx->d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->s_front));
-    CKC(hipMemcpyAsync(ctx->h_err, ctx->d_err, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->s_front));
-    CKC(hipStreamSynchronize(ctx->s_front));
+                  L, ctx->d_prev_xy, (const int*)(ctx->d_prev_xy + (size_t)2 * n), nb, n, P, ctx->dm_out_xy, ctx->dm_status, ctx->dm_err));
+    CKC(hipStreamSynchronize(ctx->s_front));   // the kernel wrote positions / status / err straight into mapped pinned memory
     memcpy(out_xy, ctx->h_out_xy, (size_t)n * 8);
     memcpy(out_status, ctx->h_status, (size_t)n);
     memcpy(out_err, ctx->h_err, (size_t)n * 4);

@@ -23,6 +23,8 @@ struct pmv_ctx {
     uint8_t* d_status = nullptr;
     float *h_prev_xy = nullptr, *h_out_xy = nullptr, *h_err = nullptr;
     uint8_t* h_status = nullptr;
+    float *dm_out_xy = nullptr, *dm_err = nullptr;   // device aliases of the mapped pinned result buffers
+    uint8_t* dm_status = nullptr;
     // detectors
     int* d_cells = nullptr;
     double* d_eig = nullptr;
