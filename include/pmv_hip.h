@@ -92,6 +92,8 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
 
 /* Debug/parity: models (n*6: rvec,tvec) and inlier counts of the first n hypotheses of the last pmv_pnp_ransac call. */
 int pmv_debug_pnp_hypotheses(pmv_ctx* ctx, int n, double* models, int* counts);
+/* diagnostic: 32 accumulated shader-clock phase timers of the back-end kernels (recorded only with PMV_BA_STAMPS=1) */
+int pmv_debug_ba_stamps(pmv_ctx* ctx, unsigned long long* out32);
 
 /* ---- bundle adjustment ------------------------------------------------------------------------------------- */
 typedef struct pmv_ba_summary {
