@@ -94,6 +94,8 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
 int pmv_debug_pnp_hypotheses(pmv_ctx* ctx, int n, double* models, int* counts);
 /* diagnostic: 32 accumulated shader-clock phase timers of the back-end kernels (recorded only with PMV_BA_STAMPS=1) */
 int pmv_debug_ba_stamps(pmv_ctx* ctx, unsigned long long* out32);
+/* diagnostic: 16 phase timers of the LK kernel, track 0 (recorded only with PMV_LK_STAMPS=1) */
+int pmv_debug_lk_stamps(pmv_ctx* ctx, unsigned long long* out16);
 
 /* ---- bundle adjustment ------------------------------------------------------------------------------------- */
 typedef struct pmv_ba_summary {

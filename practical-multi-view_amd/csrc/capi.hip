@@ -117,6 +117,7 @@ void pmv_ctx_destroy(pmv_ctx* c) {
     if (c->s_back) hipStreamSynchronize(c->s_back);
     backend_destroy(c);
     c->prof.destroy();
+    if (c->d_lk_stamps) hipFree(c->d_lk_stamps);
     hipFree(c->d_slots); hipFree(c->d_prev_xy); hipFree(c->d_out_xy); hipFree(c->d_status); hipFree(c->d_err);
     hipHostFree(c->h_prev_xy); hipHostFree(c->h_out_xy); hipHostFree(c->h_status); hipHostFree(c->h_err);
     hipFree(c->d_cells); hipFree(c->d_eig); hipFree(c->d_cellmax); hipFree(c->d_det_xy); hipFree(c->d_det_score);
@@ -253,6 +254,8 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     CKC(hipMemcpyAsync(ctx->d_prev_xy, ctx->h_prev_xy, (size_t)n * 8 + (size_t)nb * 4, hipMemcpyHostToDevice, ctx->s_front));
     LKParams P;
     P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f;
+    if (!ctx->d_lk_stamps && getenv("PMV_LK_STAMPS")) { CKC(hipMalloc(&ctx->d_lk_stamps, 16 * 8)); CKC(hipMemset(ctx->d_lk_stamps, 0, 16 * 8)); }
+    P.stamps = ctx->d_lk_stamps;
     CKC(launch_lk(ctx->s_front, ctx->d_slots + (size_t)prev_slot * L.slot_bytes, ctx->d_slots + (size_t)next_slot * L.slot_bytes,
                   L, ctx->d_prev_xy, (const int*)(ctx->d_prev_xy + (size_t)2 * n), nb, n, P, ctx->dm_out_xy, ctx->dm_status, ctx->dm_err));
     CKC(hipStreamSynchronize(ctx->s_front));   // the kernel wrote positions / status / err straight into mapped pinned memory
@@ -339,6 +342,17 @@ int pmv_prof_enable(pmv_ctx* ctx, int on) {
 int pmv_prof_select(pmv_ctx* ctx, unsigned mask) {
     REQ(ctx, PMV_ERR_INVALID, "null ctx");
     ctx->prof.mask = mask;
+    return PMV_OK;
+}
+// diagnostic: phase timers of k_lk for track 0 (PMV_LK_STAMPS=1): [0] level entry, [1] I tile, [2] Scharr, [3] samples + A, [4] iterations
+// (+ J tiles), [5] error pass; [8] iteration count
+int pmv_debug_lk_stamps(pmv_ctx* ctx, unsigned long long* out16) {
+    REQ(ctx && out16, PMV_ERR_INVALID, "null argument");
+    memset(out16, 0, 16 * 8);
+    if (!ctx->d_lk_stamps) return PMV_OK;
+    CKC(hipSetDevice(ctx->device));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    CKC(hipMemcpy(out16, ctx->d_lk_stamps, 16 * 8, hipMemcpyDeviceToHost));
     return PMV_OK;
 }
 int pmv_prof_kernel_count(void) { return K_COUNT; }

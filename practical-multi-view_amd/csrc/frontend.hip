@@ -79,7 +79,7 @@ hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int
 //   33x33 (dx,dy) int16 pairs, and a 64x64 u8 search tile of the next image that is re-staged only when the
 //   window walks out of it.
 // =========================================================================================================
-constexpr int SI_STRIDE = 40;
+constexpr int SI_STRIDE = 40;   // 40 staged bytes per row: 35 tile columns + up to 3 bytes of dword-alignment slack
 constexpr int SD_STRIDE = 33;
 constexpr int SJ_STRIDE = 68;
 
@@ -118,8 +118,11 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
     float outx = 0.f, outy = 0.f, err = 0.f;
     int status = 1;
     const int ml = L.n_levels - 1;
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#define LSTAMP(k) do { if (P.stamps && t == 0 && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); P.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
     for (int level = ml; level >= 0; level--) {
+        LSTAMP(0);
         const int lw = L.w[level], lh = L.h[level], ls = L.stride[level];
         const uint8_t* Iorg = level_origin(prevS, L, level);
         const uint8_t* Jorg = level_origin(nextS, L, level);
@@ -140,15 +143,20 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
 
         __syncthreads();
         // ---- stage the 35x35 I tile: rows ipy-1 .. ipy+33, cols ipx-1 .. ipx+33 (always inside the padded buffer)
-        for (int idx = lane; idx < 35 * 35; idx += 64) {
-            const int y = idx / 35, x = idx - y * 35;
-            sI[y * SI_STRIDE + x] = Iorg[(ptrdiff_t)(ipy - 1 + y) * ls + (ipx - 1 + x)];
+        // dword copies of 40-byte rows that start at the 4-byte-aligned column below ipx-1 (level origin, stride and PAD are
+        // multiples of 4; 35 + 3 <= 40 columns stay inside the 64-pixel frame): 350 loads instead of 1225 byte loads
+        const int ax0 = (ipx - 1) & ~3, aoff = (ipx - 1) - ax0;
+        for (int idx = lane; idx < 35 * 10; idx += 64) {
+            const int y = idx / 10, xw = idx - y * 10;
+            ((uint32_t*)(sI + y * SI_STRIDE))[xw] = *(const uint32_t*)(Iorg + (ptrdiff_t)(ipy - 1 + y) * ls + ax0 + 4 * xw);
         }
         __syncthreads();
+        const uint8_t* sIo = sI + aoff;   // tile origin (ipx-1, ipy-1)
+        LSTAMP(1);
         // ---- Scharr (calcSharrDeriv) at the 33x33 sample positions; constant 0 outside the image
         for (int idx = lane; idx < 33 * 33; idx += 64) {
             const int y = idx / 33, x = idx - y * 33;
-            const uint8_t* c = &sI[(y + 1) * SI_STRIDE + (x + 1)];
+            const uint8_t* c = &sIo[(y + 1) * SI_STRIDE + (x + 1)];
             const int gx = ipx + x, gy = ipy + y;
             short2 d = make_short2(0, 0);
             if (gx >= 0 && gx < lw && gy >= 0 && gy < lh) {
@@ -163,11 +171,12 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
             sD[y * SD_STRIDE + x] = d;
         }
         __syncthreads();
+        LSTAMP(2);
         // ---- this lane's 16 window samples (I with 5 fractional bits, Ix, Iy) + exact A sums
         int Iv[16], Ix[16], Iy[16];
         int a11 = 0, a12 = 0, a22 = 0;   // per-lane partials fit int32: 16 * 4080^2 < 2^31
         {
-            const uint8_t* i0 = &sI[(r + 1) * SI_STRIDE + (c0 + 1)];
+            const uint8_t* i0 = &sIo[(r + 1) * SI_STRIDE + (c0 + 1)];
             const short2* d0 = &sD[r * SD_STRIDE + c0];
             int p0 = i0[0], p1 = i0[SI_STRIDE];
             short2 q0 = d0[0], q1 = d0[SD_STRIDE];
@@ -175,11 +184,12 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
             for (int k = 0; k < 16; k++) {
                 const int p0n = i0[k + 1], p1n = i0[SI_STRIDE + k + 1];
                 const short2 q0n = d0[k + 1], q1n = d0[SD_STRIDE + k + 1];
-                Iv[k] = descale(p0 * iw00 + p0n * iw01 + p1 * iw10 + p1n * iw11, 9);
-                const int ixv = descale(q0.x * iw00 + q0n.x * iw01 + q1.x * iw10 + q1n.x * iw11, 14);
-                const int iyv = descale(q0.y * iw00 + q0n.y * iw01 + q1.y * iw10 + q1n.y * iw11, 14);
+                // every factor fits 24 bits (pixels 8, weights 15, derivatives 13): v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter
+                Iv[k] = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9);
+                const int ixv = descale(__mul24(q0.x, iw00) + __mul24(q0n.x, iw01) + __mul24(q1.x, iw10) + __mul24(q1n.x, iw11), 14);
+                const int iyv = descale(__mul24(q0.y, iw00) + __mul24(q0n.y, iw01) + __mul24(q1.y, iw10) + __mul24(q1n.y, iw11), 14);
                 Ix[k] = ixv; Iy[k] = iyv;
-                a11 += ixv * ixv; a12 += ixv * iyv; a22 += iyv * iyv;
+                a11 += __mul24(ixv, ixv); a12 += __mul24(ixv, iyv); a22 += __mul24(iyv, iyv);
                 p0 = p0n; p1 = p1n; q0 = q0n; q1 = q1n;
             }
         }
@@ -192,6 +202,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
             continue;
         }
         D = 1.f / D;
+        LSTAMP(3);
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
         int tx0 = 0, ty0 = 0;
@@ -220,8 +231,8 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
-                    const int diff = descale(p0 * iw00 + p0n * iw01 + p1 * iw10 + p1n * iw11, 9) - Iv[k];
-                    b1 += diff * Ix[k]; b2 += diff * Iy[k];
+                    const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
+                    b1 += __mul24(diff, Ix[k]); b2 += __mul24(diff, Iy[k]);
                     p0 = p0n; p1 = p1n;
                 }
             }
@@ -236,7 +247,9 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
                 break;
             }
             pdx = dx; pdy = dy;
+            if (P.stamps && t == 0 && lane == 0) P.stamps[8] += 1;
         }
+        LSTAMP(4);
 
         if (status && level == 0) {
             const float fx = outx - half, fy = outy - half;
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
-                    const int diff = descale(p0 * iw00 + p0n * iw01 + p1 * iw10 + p1n * iw11, 9) - Iv[k];
+                    const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
                     e += diff < 0 ? -diff : diff;
                     p0 = p0n; p1 = p1n;
                 }
@@ -267,6 +280,8 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
             }
         }
     }
+    LSTAMP(5);
+#undef LSTAMP
     if (lane == 0) {
         out_xy[2 * t] = outx; out_xy[2 * t + 1] = outy;
         out_status[t] = (uint8_t)status;

@@ -25,6 +25,7 @@ struct pmv_ctx {
     uint8_t* h_status = nullptr;
     float *dm_out_xy = nullptr, *dm_err = nullptr;   // device aliases of the mapped pinned result buffers
     uint8_t* dm_status = nullptr;
+    unsigned long long* d_lk_stamps = nullptr;   // diagnostic (PMV_LK_STAMPS=1)
     // detectors
     int* d_cells = nullptr;
     double* d_eig = nullptr;
