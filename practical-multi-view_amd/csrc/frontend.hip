@@ -73,9 +73,9 @@ hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int
 }
 
 // =========================================================================================================
-// Pyramidal Lucas–Kanade: one wavefront per track, all levels inside one launch.
-//   lane l owns window row (l>>1), columns (l&1)*16 .. +15; its 16 (I, Ix, Iy) samples live in registers.
-//   LDS per wave: 35x35 u8 tile of the previous image (-> Scharr on the fly, no derivative image in HBM),
+// Pyramidal Lucas–Kanade: one 256-thread block (4 wavefronts) per track, all levels inside one launch.
+//   thread = window row (tid >> 3), 4 consecutive columns; its (I, Ix, Iy) samples live in registers for the level.
+//   LDS per block: 35x35 u8 tile of the previous image (-> Scharr on the fly, no derivative image in HBM),
 //   33x33 (dx,dy) int16 pairs, and a 64x64 u8 search tile of the next image that is re-staged only when the
 //   window walks out of it.
 // =========================================================================================================
@@ -92,34 +92,65 @@ __device__ inline void bilinear_weights(float a, float b, int& w00, int& w01, in
     w11 = 16384 - w00 - w01 - w10;
 }
 
-__device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0, int ty0, int lane) {
-    // lane = tile row; 64 bytes per row, dword-aligned (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0)
-    const uint32_t* g = (const uint32_t*)(Jorg + (ptrdiff_t)(ty0 + lane) * js + tx0);
-    uint32_t* d = (uint32_t*)(sJ + lane * SJ_STRIDE);
+// Block-wide EXACT sums of per-thread int32 partials (4 wavefronts). The partials are converted to double: every partial sum of
+// these integers stays far below 2^53 (<= 1024 pixels x 8160 x 4080 = 3.4e10), so double addition is exact in any order — one
+// DPP reduction per value instead of the hi/lo int32 pair. Each wavefront leaves its total in LDS and after ONE barrier every
+// thread adds the four totals. `slot` alternates between calls that are not separated by another barrier (iteration parity),
+// so the next write never overtakes a pending read. (float)(total) rounds the exact integer once, like (float)(int64).
+constexpr int LK_T = 256, LK_NW = LK_T / 64;
+template <int N>
+__device__ inline void block_sum_exact(const int (&part)[N], double (&out)[N], double* sred /* [2][LK_NW][4] */, int slot) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = g[k];
+    for (int k = 0; k < N; k++) {
+        const double v = wave_sum_f64((double)part[k]);
+        if (lane == 0) sred[(slot * LK_NW + wv) * 4 + k] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double a = sred[(slot * LK_NW + 0) * 4 + k];
+#pragma unroll
+        for (int w = 1; w < LK_NW; w++) a += sred[(slot * LK_NW + w) * 4 + k];
+        out[k] = a;
+    }
 }
 
-__global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS,
-                                           PyrLayout L, const float* __restrict__ prev_xy, const int* __restrict__ order, int n, LKParams P,
-                                           float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
-                                           float* __restrict__ out_err) {
+// 64x64-byte search tile, dword copies (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0): 1024 dwords over 256 threads
+__device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0, int ty0, int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int idx = tid + q * LK_T, row = idx >> 4, xw = idx & 15;
+        ((uint32_t*)(sJ + row * SJ_STRIDE))[xw] = *(const uint32_t*)(Jorg + (ptrdiff_t)(ty0 + row) * js + tx0 + 4 * xw);
+    }
+}
+
+// One 256-thread block (4 wavefronts) per track: thread = window row (tid >> 3) and 4 consecutive columns ((tid & 7) * 4); its
+// (I, Ix, Iy) samples live in registers for the whole level. A single wavefront per track is VALU-issue-bound (2.2 k cycles per
+// iteration for 16 pixels per lane); four wavefronts on the four SIMDs of a CU cut the per-iteration chain to 4 pixels per lane
+// plus one barrier. All sums are integers (order-free), so the result is bit-identical to the sequential algorithm.
+__global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS,
+                                             PyrLayout L, const float* __restrict__ prev_xy, const int* __restrict__ order, int n, LKParams P,
+                                             float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
+                                             float* __restrict__ out_err) {
     __shared__ __attribute__((aligned(16))) uint8_t sI[35 * SI_STRIDE];
     __shared__ __attribute__((aligned(16))) short2 sD[33 * SD_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t sJ[64 * SJ_STRIDE];
+    __shared__ double sred[2 * LK_NW * 4];
     const int t = order[blockIdx.x];   // block -> track (XCD-aware order built by the host; -1 = no track)
     if (t < 0 || t >= n) return;
-    const int lane = threadIdx.x;
-    const int r = lane >> 1, c0 = (lane & 1) * 16;
+    const int tid = threadIdx.x;
+    const int r = tid >> 3, c0 = (tid & 7) * 4;
     const float px0 = prev_xy[2 * t], py0 = prev_xy[2 * t + 1];
     const int W = LK_WIN;
     const float half = 15.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     float outx = 0.f, outy = 0.f, err = 0.f;
     int status = 1;
+    int slot = 0;
     const int ml = L.n_levels - 1;
     unsigned long long t_prev = __builtin_readcyclecounter();
-#define LSTAMP(k) do { if (P.stamps && t == 0 && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); P.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
+#define LSTAMP(k) do { if (P.stamps && t == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); P.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
     for (int level = ml; level >= 0; level--) {
         LSTAMP(0);
@@ -134,7 +165,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
         outx = nx; outy = ny;
         prevx -= half; prevy -= half;
         const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
-        if (ipx < -W || ipx >= lw || ipy < -W || ipy >= lh) {
+        if (ipx < -W || ipx >= lw || ipy < -W || ipy >= lh) {   // block-uniform
             if (level == 0) { status = 0; err = 0.f; }
             continue;
         }
@@ -142,11 +173,10 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
         bilinear_weights(prevx - ipx, prevy - ipy, iw00, iw01, iw10, iw11);
 
         __syncthreads();
-        // ---- stage the 35x35 I tile: rows ipy-1 .. ipy+33, cols ipx-1 .. ipx+33 (always inside the padded buffer)
-        // dword copies of 40-byte rows that start at the 4-byte-aligned column below ipx-1 (level origin, stride and PAD are
-        // multiples of 4; 35 + 3 <= 40 columns stay inside the 64-pixel frame): 350 loads instead of 1225 byte loads
+        // ---- stage the 35x35 I tile (rows ipy-1 .. ipy+33, cols ipx-1 .. ipx+33, always inside the padded buffer) as dword copies of
+        // 40-byte rows that start at the 4-byte-aligned column below ipx-1 (35 + 3 <= 40 columns stay inside the 64-pixel frame)
         const int ax0 = (ipx - 1) & ~3, aoff = (ipx - 1) - ax0;
-        for (int idx = lane; idx < 35 * 10; idx += 64) {
+        for (int idx = tid; idx < 35 * 10; idx += LK_T) {
             const int y = idx / 10, xw = idx - y * 10;
             ((uint32_t*)(sI + y * SI_STRIDE))[xw] = *(const uint32_t*)(Iorg + (ptrdiff_t)(ipy - 1 + y) * ls + ax0 + 4 * xw);
         }
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
         const uint8_t* sIo = sI + aoff;   // tile origin (ipx-1, ipy-1)
         LSTAMP(1);
         // ---- Scharr (calcSharrDeriv) at the 33x33 sample positions; constant 0 outside the image
-        for (int idx = lane; idx < 33 * 33; idx += 64) {
+        for (int idx = tid; idx < 33 * 33; idx += LK_T) {
             const int y = idx / 33, x = idx - y * 33;
             const uint8_t* c = &sIo[(y + 1) * SI_STRIDE + (x + 1)];
             const int gx = ipx + x, gy = ipy + y;
@@ -172,16 +202,16 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
         }
         __syncthreads();
         LSTAMP(2);
-        // ---- this lane's 16 window samples (I with 5 fractional bits, Ix, Iy) + exact A sums
-        int Iv[16], Ix[16], Iy[16];
-        int a11 = 0, a12 = 0, a22 = 0;   // per-lane partials fit int32: 16 * 4080^2 < 2^31
+        // ---- this thread's 4 window samples (I with 5 fractional bits, Ix, Iy) + exact A sums
+        int Iv[4], Ix[4], Iy[4];
+        int apart[3] = {0, 0, 0};
         {
             const uint8_t* i0 = &sIo[(r + 1) * SI_STRIDE + (c0 + 1)];
             const short2* d0 = &sD[r * SD_STRIDE + c0];
             int p0 = i0[0], p1 = i0[SI_STRIDE];
             short2 q0 = d0[0], q1 = d0[SD_STRIDE];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < 4; k++) {
                 const int p0n = i0[k + 1], p1n = i0[SI_STRIDE + k + 1];
                 const short2 q0n = d0[k + 1], q1n = d0[SD_STRIDE + k + 1];
                 // every factor fits 24 bits (pixels 8, weights 15, derivatives 13): v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter
@@ -189,15 +219,16 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
                 const int ixv = descale(__mul24(q0.x, iw00) + __mul24(q0n.x, iw01) + __mul24(q1.x, iw10) + __mul24(q1n.x, iw11), 14);
                 const int iyv = descale(__mul24(q0.y, iw00) + __mul24(q0n.y, iw01) + __mul24(q1.y, iw10) + __mul24(q1n.y, iw11), 14);
                 Ix[k] = ixv; Iy[k] = iyv;
-                a11 += __mul24(ixv, ixv); a12 += __mul24(ixv, iyv); a22 += __mul24(iyv, iyv);
+                apart[0] += __mul24(ixv, ixv); apart[1] += __mul24(ixv, iyv); apart[2] += __mul24(iyv, iyv);
                 p0 = p0n; p1 = p1n; q0 = q0n; q1 = q1n;
             }
         }
-        const long long sA11 = wave_sum_i32_wide(a11), sA12 = wave_sum_i32_wide(a12), sA22 = wave_sum_i32_wide(a22);
-        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        double sA[3];
+        block_sum_exact<3>(apart, sA, sred, slot); slot ^= 1;
+        const float A11 = (float)sA[0] * FLT_SCALE, A12 = (float)sA[1] * FLT_SCALE, A22 = (float)sA[2] * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * W * W);
-        if (minEig < P.min_eig || D < FLT_EPSILON) {
+        if (minEig < P.min_eig || D < FLT_EPSILON) {   // block-uniform (computed from block-wide sums)
             if (level == 0) status = 0;
             continue;
         }
@@ -218,36 +249,42 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
             if (!have_tile || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
                 tx0 = (inx - 16) & ~3; ty0 = iny - 16;
                 __syncthreads();
-                stage_J(sJ, Jorg, ls, tx0, ty0, lane);
+                stage_J(sJ, Jorg, ls, tx0, ty0, tid);
                 __syncthreads();
                 have_tile = true;
                 wx = inx - tx0; wy = iny - ty0;
             }
+            LSTAMP(9);
             bilinear_weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
-            int b1 = 0, b2 = 0;          // per-lane partials fit int32: 16 * 8160 * 4080 < 2^31
+            int bpart[2] = {0, 0};
             {
                 const uint8_t* j0 = &sJ[(wy + r) * SJ_STRIDE + wx + c0];
                 int p0 = j0[0], p1 = j0[SJ_STRIDE];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
+                for (int k = 0; k < 4; k++) {
                     const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
                     const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
-                    b1 += __mul24(diff, Ix[k]); b2 += __mul24(diff, Iy[k]);
+                    bpart[0] += __mul24(diff, Ix[k]); bpart[1] += __mul24(diff, Iy[k]);
                     p0 = p0n; p1 = p1n;
                 }
             }
-            const float fb1 = (float)wave_sum_i32_wide(b1) * FLT_SCALE, fb2 = (float)wave_sum_i32_wide(b2) * FLT_SCALE;
+            LSTAMP(10);
+            double sB[2];
+            block_sum_exact<2>(bpart, sB, sred, slot); slot ^= 1;
+            LSTAMP(11);
+            const float fb1 = (float)sB[0] * FLT_SCALE, fb2 = (float)sB[1] * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nx += dx; ny += dy;
             outx = nx + half; outy = ny + half;
+            if (P.stamps && t == 0 && tid == 0) P.stamps[8] += 1;
             if ((double)dx * dx + (double)dy * dy <= P.eps2d) break;
             if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
                 break;
             }
             pdx = dx; pdy = dy;
-            if (P.stamps && t == 0 && lane == 0) P.stamps[8] += 1;
+            LSTAMP(12);
         }
         LSTAMP(4);
 
@@ -261,28 +298,30 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t* __restrict__ prevS, co
                 if (!have_tile || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
                     tx0 = (inx - 16) & ~3; ty0 = iny - 16;
                     __syncthreads();
-                    stage_J(sJ, Jorg, ls, tx0, ty0, lane);
+                    stage_J(sJ, Jorg, ls, tx0, ty0, tid);
                     __syncthreads();
                     wx = inx - tx0; wy = iny - ty0;
                 }
                 bilinear_weights(fx - inx, fy - iny, iw00, iw01, iw10, iw11);
-                int e = 0;
+                int epart[1] = {0};
                 const uint8_t* j0 = &sJ[(wy + r) * SJ_STRIDE + wx + c0];
                 int p0 = j0[0], p1 = j0[SJ_STRIDE];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
+                for (int k = 0; k < 4; k++) {
                     const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
                     const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
-                    e += diff < 0 ? -diff : diff;
+                    epart[0] += diff < 0 ? -diff : diff;
                     p0 = p0n; p1 = p1n;
                 }
-                err = (float)wave_sum_i32(e) * (1.f / (32 * W * W));   // <= 1024 * 8160 fits int32
+                double sE[1];
+                block_sum_exact<1>(epart, sE, sred, slot); slot ^= 1;
+                err = (float)sE[0] * (1.f / (32 * W * W));
             }
         }
     }
     LSTAMP(5);
 #undef LSTAMP
-    if (lane == 0) {
+    if (tid == 0) {
         out_xy[2 * t] = outx; out_xy[2 * t + 1] = outy;
         out_status[t] = (uint8_t)status;
         out_err[t] = err;
@@ -294,7 +333,7 @@ hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* nex
                      uint8_t* d_status, float* d_err) {
     if (n <= 0) return hipSuccess;
     ProfScope ps(K_LK, s);
-    hipLaunchKernelGGL(k_lk, dim3(n_blocks), dim3(64), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
+    hipLaunchKernelGGL(k_lk, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
     return hipGetLastError();
 }
 

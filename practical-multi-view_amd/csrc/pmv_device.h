@@ -60,6 +60,29 @@ __device__ inline long long wave_sum_i32_wide(int v) {
     const int hi = wave_sum_i32(v >> 16), lo = wave_sum_i32(v & 0xffff);
     return (long long)hi * 65536 + lo;
 }
+// Wavefront all-reduce of doubles on DPP row operations (a ds_bpermute shuffle of an f64 costs ~160 clk per step, a DPP move
+// ~10): quad butterflies, row_half_mirror, row_mirror give every lane its 16-lane row sum; the four row sums are fetched with
+// lane reads and added in a fixed order. Every lane receives the same bits.
+__device__ inline double dpp_f64(double v, const int ctrl_sel) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_sel) {   // the DPP control must be an immediate
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, false); break;
+    }
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double readlane_f64_c(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ inline double wave_sum_f64(double v) {
+    v += dpp_f64(v, 0);   // quad_perm [1,0,3,2]
+    v += dpp_f64(v, 1);   // quad_perm [2,3,0,1]
+    v += dpp_f64(v, 2);   // row_half_mirror
+    v += dpp_f64(v, 3);   // row_mirror
+    return (readlane_f64_c(v, 0) + readlane_f64_c(v, 16)) + (readlane_f64_c(v, 32) + readlane_f64_c(v, 48));
+}
 __device__ inline unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -19,3 +19,5 @@ out = np.zeros(16, np.uint64)
 ctx.lib.pmv_debug_lk_stamps(ctx.h, out.ctypes.data_as(C.POINTER(C.c_uint64)))
 names = ["level-entry", "I-tile", "scharr", "samples+A", "iterations(+J tiles)", "err-pass"]
 print("tracks", len(pts), "calls", calls, " ".join("%s=%d" % (nm, int(out[i]) / calls) for i, nm in enumerate(names)), "iterations/call %.1f" % (int(out[8]) / calls), "cycles per call")
+it = max(1, int(out[8]))
+print("per iteration: top(tile check)=%d sample+diff=%d block-sum=%d update=%d cycles" % tuple(int(out[k]) / it for k in (9, 10, 11, 12)))
