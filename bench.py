@@ -206,7 +206,13 @@ def main():
             if dom in tj.get("kernels", {}):
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
                 traffic_src = tj.get("source")
-        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 4), peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
+        limiter = {
+            "k_lk": "latency: ~2.2k-cycle dependent chain per LK iteration (exact reduction + barrier + scalar update); a launch ends with its slowest track",
+            "k_pnp_hyp": "latency: serial FP64 algebra of 5-point EPnP (12x12 Jacobi, pseudo-inverses, Gauss-Newton), one wavefront per hypothesis",
+            "k_pnp_select_refit": "latency: sequential LM passes of the refit",
+            "k_gftt_select": "latency: sequential arg-max / suppression rounds per cell",
+        }.get(dom, "")
+        roofline = dict(bound="hbm", kernel=dom, limiter=limiter, achieved=round(achieved, 4), peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
                         traffic=traffic, traffic_source=traffic_src, avg_launch_us=round(avg_s * 1e6, 3), algorithmic_bytes_per_launch=round(per_launch_bytes.get(dom, 0.0), 1))
 
     # ---- PCIe-inclusive variant (never `value`): the same step when the caller hands over HOST frames — staging the gray frames
