@@ -352,25 +352,33 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
         double L[60], rho[6], betas[4];
         for (int i = 0; i < 60; i++) L[i] = sh.L[i];
         for (int i = 0; i < 6; i++) rho[i] = sh.rho[i];
+        // find_betas_approx_1/2/3: least squares on 4 / 3 / 5 columns of L_6x10. The three lanes run ONE code path (lanes of a
+        // wavefront that take different paths execute them one after the other): the 6x4 and 6x3 systems are padded with zero
+        // columns to 6x5. Padding is exact: the padded rows/columns of A^T A are zero and stay zero, the cyclic Jacobi skips
+        // their pairs (apq == 0), which leaves exactly the rotation sequence of the smaller matrix; the padded eigenvalue 0 is
+        // below the singular-value threshold and contributes nothing.
+        double l5[30], b5[5];
+        {
+            const int c0 = 0, c1 = 1, c2 = (N == 1) ? 3 : 2, c3 = (N == 1) ? 6 : ((N == 3) ? 3 : -1), c4 = (N == 3) ? 4 : -1;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                l5[i * 5 + 0] = sh.L[i * 10 + c0];
+                l5[i * 5 + 1] = sh.L[i * 10 + c1];
+                l5[i * 5 + 2] = sh.L[i * 10 + c2];
+                l5[i * 5 + 3] = (c3 >= 0) ? sh.L[i * 10 + (c3 >= 0 ? c3 : 0)] : 0.0;
+                l5[i * 5 + 4] = (c4 >= 0) ? sh.L[i * 10 + (c4 >= 0 ? c4 : 0)] : 0.0;
+            }
+        }
+        d_pinv_solve<6, 5>(l5, rho, b5);
         if (N == 1) {
-            double l4[24], b4[4];
-            for (int i = 0; i < 6; i++) { l4[i * 4] = L[i * 10]; l4[i * 4 + 1] = L[i * 10 + 1]; l4[i * 4 + 2] = L[i * 10 + 3]; l4[i * 4 + 3] = L[i * 10 + 6]; }
-            d_pinv_solve<6, 4>(l4, rho, b4);
-            if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
-            else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
+            if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = -b5[1] / betas[0]; betas[2] = -b5[2] / betas[0]; betas[3] = -b5[3] / betas[0]; }
+            else { betas[0] = sqrt(b5[0]); betas[1] = b5[1] / betas[0]; betas[2] = b5[2] / betas[0]; betas[3] = b5[3] / betas[0]; }
         } else if (N == 2) {
-            double l3[18], b3[3];
-            for (int i = 0; i < 6; i++) { l3[i * 3] = L[i * 10]; l3[i * 3 + 1] = L[i * 10 + 1]; l3[i * 3 + 2] = L[i * 10 + 2]; }
-            d_pinv_solve<6, 3>(l3, rho, b3);
-            if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
-            else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
-            if (b3[1] < 0) betas[0] = -betas[0];
+            if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+            else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+            if (b5[1] < 0) betas[0] = -betas[0];
             betas[2] = 0.0; betas[3] = 0.0;
         } else {
-            double l5[30], b5[5];
-            for (int i = 0; i < 6; i++)
-                for (int j = 0; j < 5; j++) l5[i * 5 + j] = L[i * 10 + j];
-            d_pinv_solve<6, 5>(l5, rho, b5);
             if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
             else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
             if (b5[1] < 0) betas[0] = -betas[0];
