@@ -166,16 +166,18 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
 #define HSTAMP(k) do { if (stamps && h == 0 && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
     const double fu = K[0], fv = K[4], uc = K[2], vc = K[5];
     const int n = 5;
-    if (lane == 0) {
+    if (lane < n) {   // the five sample points, one lane each (two dependent global round trips instead of ten)
         const double ifx = 1. / fu, ify = 1. / fv;
-        for (int i = 0; i < n; i++) {
-            const int s = samples[h * 5 + i];
-            sh.pws[3 * i] = obj[3 * s]; sh.pws[3 * i + 1] = obj[3 * s + 1]; sh.pws[3 * i + 2] = obj[3 * s + 2];
-            const float xn = (float)(((double)img[2 * s] - uc) * ifx);
-            const float yn = (float)(((double)img[2 * s + 1] - vc) * ify);
-            sh.us[2 * i] = xn * fu + uc;
-            sh.us[2 * i + 1] = yn * fv + vc;
-        }
+        const int i = lane;
+        const int s = samples[h * 5 + i];
+        sh.pws[3 * i] = obj[3 * s]; sh.pws[3 * i + 1] = obj[3 * s + 1]; sh.pws[3 * i + 2] = obj[3 * s + 2];
+        const float xn = (float)(((double)img[2 * s] - uc) * ifx);
+        const float yn = (float)(((double)img[2 * s + 1] - vc) * ify);
+        sh.us[2 * i] = xn * fu + uc;
+        sh.us[2 * i + 1] = yn * fv + vc;
+    }
+    WAVE_SYNC_PNP();
+    if (lane == 0) {
         // choose_control_points
         double* cws = sh.cws;
         cws[0] = cws[1] = cws[2] = 0;
@@ -310,39 +312,25 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
         }
         for (int i = 0; i < 4; i++)
             for (int k = 0; k < 12; k++) sh.v4[i * 12 + k] = sh.V[k * 12 + ord[i]];
-        // compute_L_6x10, compute_rho
-        double* L = sh.L;
+        const double* cws = sh.cws;   // compute_rho
         double* rho = sh.rho;
-        {
-            double dv[4][6][3];
-            for (int i = 0; i < 4; i++) {
-                const double* v = sh.v4 + 12 * i;
-                int a = 0, b = 1;
-                for (int j = 0; j < 6; j++) {
-                    dv[i][j][0] = v[3 * a] - v[3 * b];
-                    dv[i][j][1] = v[3 * a + 1] - v[3 * b + 1];
-                    dv[i][j][2] = v[3 * a + 2] - v[3 * b + 2];
-                    b++;
-                    if (b > 3) { a++; b = a + 1; }
-                }
-            }
-            for (int i = 0; i < 6; i++) {
-                double* row = L + 10 * i;
-                row[0] = d_dot3(dv[0][i], dv[0][i]);
-                row[1] = 2.0f * d_dot3(dv[0][i], dv[1][i]);
-                row[2] = d_dot3(dv[1][i], dv[1][i]);
-                row[3] = 2.0f * d_dot3(dv[0][i], dv[2][i]);
-                row[4] = 2.0f * d_dot3(dv[1][i], dv[2][i]);
-                row[5] = d_dot3(dv[2][i], dv[2][i]);
-                row[6] = 2.0f * d_dot3(dv[0][i], dv[3][i]);
-                row[7] = 2.0f * d_dot3(dv[1][i], dv[3][i]);
-                row[8] = 2.0f * d_dot3(dv[2][i], dv[3][i]);
-                row[9] = d_dot3(dv[3][i], dv[3][i]);
-            }
-            const double* cws = sh.cws;
-            rho[0] = d_dist2(cws, cws + 3); rho[1] = d_dist2(cws, cws + 6); rho[2] = d_dist2(cws, cws + 9);
-            rho[3] = d_dist2(cws + 3, cws + 6); rho[4] = d_dist2(cws + 3, cws + 9); rho[5] = d_dist2(cws + 6, cws + 9);
-        }
+        rho[0] = d_dist2(cws, cws + 3); rho[1] = d_dist2(cws, cws + 6); rho[2] = d_dist2(cws, cws + 9);
+        rho[3] = d_dist2(cws + 3, cws + 6); rho[4] = d_dist2(cws + 3, cws + 9); rho[5] = d_dist2(cws + 6, cws + 9);
+    }
+    WAVE_SYNC_PNP();
+    if (lane < 60) {
+        // compute_L_6x10, one entry per lane: row i = control-point pair (a,b), column k = product of the difference vectors of
+        // null-space vectors (u,w) in epnp's order 00 01 11 02 12 22 03 13 23 33 (off-diagonal ones doubled)
+        const int i = lane / 10, k = lane - i * 10;
+        const int pa = (i < 3) ? 0 : ((i < 5) ? 1 : 2), pb = (i < 3) ? i + 1 : ((i < 5) ? i - 1 : 3);
+        const int u = (k == 0 || k == 1 || k == 3 || k == 6) ? 0 : ((k == 2 || k == 4 || k == 7) ? 1 : ((k == 5 || k == 8) ? 2 : 3));
+        const int w = (k == 0) ? 0 : ((k == 1 || k == 2) ? 1 : ((k == 3 || k == 4 || k == 5) ? 2 : 3));
+        const double* vu = sh.v4 + 12 * u;
+        const double* vw = sh.v4 + 12 * w;
+        const double du[3] = {vu[3 * pa] - vu[3 * pb], vu[3 * pa + 1] - vu[3 * pb + 1], vu[3 * pa + 2] - vu[3 * pb + 2]};
+        const double dw[3] = {vw[3 * pa] - vw[3 * pb], vw[3 * pa + 1] - vw[3 * pb + 1], vw[3 * pa + 2] - vw[3 * pb + 2]};
+        const double d = d_dot3(du, dw);
+        sh.L[i * 10 + k] = (u == w) ? d : 2.0f * d;
     }
     __syncthreads();
     HSTAMP(24);
