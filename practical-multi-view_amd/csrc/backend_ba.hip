@@ -769,7 +769,9 @@ __device__ inline void bam_decide(BAGState& s, const double* __restrict__ part4,
     bool valid = s.step_valid != 0;
     double mc = 0, cc = 0, dn2 = 0;
     if (valid) {
-        for (int b = 0; b < nbp; b++) { mc += part4[b * 4]; cc += part4[b * 4 + 1]; dn2 += part4[b * 4 + 2]; }
+        double xn2 = 0;
+        for (int b = 0; b < nbp; b++) { mc += part4[b * 4]; cc += part4[b * 4 + 1]; dn2 += part4[b * 4 + 2]; xn2 += part4[b * 4 + 3]; }
+        s.x_norm = sqrt(xn2);   // |x| of the point the step was taken from (summed by the back-substitution kernel)
         s.model_change = mc;
         valid = mc > 0.0;
     }
@@ -1172,14 +1174,13 @@ __device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const int* 
     double* S = dyn; double* dg = dyn + (size_t)(m + 1) * m;   // S: (m+1) x m, row m = right-hand side; dg: 1 / diagonal of L
     const double* x = A.x + (size_t)ss.cur * n;
     if (ss.need_eval) {   // block-uniform
-        double xn = 0, g = 0, cs = 0;
-        for (int i = tid; i < n; i += BM_T) xn += x[i] * x[i];
+        double g = 0, cs = 0;
         for (int i = tid; i < m; i += BM_T) g = fmax(g, fabs(rhsblk[i] / A.scale[i]));
         for (int i = tid; i < nbp; i += BM_T) g = fmax(g, part_gmax[i]);
         for (int i = tid; i < nbo; i += BM_T) cs += part_cost[i];
-        xn = wave_sum_f64(xn); cs = wave_sum_f64(cs);
+        cs = wave_sum_f64(cs);
         g = wave_max_f64(g);
-        if (lane == 0) { red[wid] = xn; red[BM_NW + wid] = cs; red[2 * BM_NW + wid] = g; }
+        if (lane == 0) { red[BM_NW + wid] = cs; red[2 * BM_NW + wid] = g; }
         __syncthreads();
         if (tid == 0) {
             if (ss.first) {   // cost of the starting point (E0); later x_cost is the accepted candidate's cost
@@ -1187,7 +1188,6 @@ __device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const int* 
                 ss.x_cost = st->x_cost = c;
                 ss.initial_cost = st->initial_cost = c;
             }
-            ss.x_norm = st->x_norm = sqrt((red[0] + red[1]) + (red[2] + red[3]));
             ss.gmax = st->gmax = fmax(fmax(red[2 * BM_NW], red[2 * BM_NW + 1]), fmax(red[2 * BM_NW + 2], red[2 * BM_NW + 3]));
         }
     }
@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(BM_T) void k_bam_solve(BAArgs A, BAGState* st, cons
 // candidate point; phase C, per observation: model-cost-change and candidate-cost terms. Partials per block, fixed order.
 __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, const double* __restrict__ candrot,
                                         double* __restrict__ tmp3, double* __restrict__ part4, int bid) {
-    __shared__ double red[3 * BM_NW];
+    __shared__ double red[4 * BM_NW];
     __shared__ double sP[BM_PB * 6];   // per point of the block: step (3), candidate point (3)
     if (st->done || !st->step_valid) return;
     const int tid = threadIdx.x;
@@ -1396,7 +1396,7 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
     const bool spec = st->iter + 1 < st->max_iterations;         // after the last iteration nobody reads them
     const int p0 = bid * BM_PB, p1 = min(A.np, p0 + BM_PB);
     const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
-    double mc = 0, cc = 0, dn2 = 0;
+    double mc = 0, cc = 0, dn2 = 0, xn2 = 0;
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
         const int i = A.pobs_list[e];
         const int c = A.cam_idx[i];
@@ -1422,7 +1422,9 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
             const double sp = -(Ei[a * 3] * t3[0] + Ei[a * 3 + 1] * t3[1] + Ei[a * 3 + 2] * t3[2]);
             A.step[m + 3 * p + a] = sp;
             const double d = sp * A.scale[m + 3 * p + a];
-            const double xp = x[m + 3 * p + a] + d;
+            const double xo = x[m + 3 * p + a];
+            xn2 += xo * xo;
+            const double xp = xo + d;
             cand[m + 3 * p + a] = xp;
             sP[tid * 6 + a] = sp; sP[tid * 6 + 3 + a] = xp;
             dn2 += d * d;
@@ -1477,15 +1479,17 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
             const double d = A.step[i] * A.scale[i];
             cand[i] = x[i] + d;
             dn2 += d * d;
+            xn2 += x[i] * x[i];
         }
     }
-    mc = wave_sum_f64(mc); cc = wave_sum_f64(cc); dn2 = wave_sum_f64(dn2);
-    if ((tid & 63) == 0) { red[tid >> 6] = mc; red[BM_NW + (tid >> 6)] = cc; red[2 * BM_NW + (tid >> 6)] = dn2; }
+    mc = wave_sum_f64(mc); cc = wave_sum_f64(cc); dn2 = wave_sum_f64(dn2); xn2 = wave_sum_f64(xn2);
+    if ((tid & 63) == 0) { red[tid >> 6] = mc; red[BM_NW + (tid >> 6)] = cc; red[2 * BM_NW + (tid >> 6)] = dn2; red[3 * BM_NW + (tid >> 6)] = xn2; }
     __syncthreads();
     if (tid == 0) {
         part4[bid * 4] = (red[0] + red[1]) + (red[2] + red[3]);
         part4[bid * 4 + 1] = (red[BM_NW] + red[BM_NW + 1]) + (red[BM_NW + 2] + red[BM_NW + 3]);
         part4[bid * 4 + 2] = (red[2 * BM_NW] + red[2 * BM_NW + 1]) + (red[2 * BM_NW + 2] + red[2 * BM_NW + 3]);
+        part4[bid * 4 + 3] = (red[3 * BM_NW] + red[3 * BM_NW + 1]) + (red[3 * BM_NW + 2] + red[3 * BM_NW + 3]);
     }
     BSTAMP(13);
 #undef BSTAMP
