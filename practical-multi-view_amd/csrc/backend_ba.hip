@@ -910,6 +910,8 @@ constexpr int BM_PB = 64;   // points per block
 __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* __restrict__ chol_flag, int pb,
                                       double* __restrict__ part_gmax, double* sEi /* [BM_PB][9] */) {
     if (st.done) return;
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#define PSTAMP(k) do { if (A.stamps && pb == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); A.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
     double* Jb = A.J + (size_t)st.cur * A.nobs * 18;
     const double* resb = A.res + (size_t)st.cur * A.nobs * 2;
     const int m = 6 * A.nc, krows = A.krows;
@@ -1009,7 +1011,9 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
     }
     gmax_p = wave_max_f64(gmax_p);
     if (tid == 0) part_gmax[pb] = gmax_p;   // the points of the block live in wavefront 0
+    PSTAMP(4);
     __syncthreads();                        // E^-1 (and, first iteration, the point scales) in LDS
+    PSTAMP(5);
     const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
     if (st.first) {   // block-uniform: one thread per observation rescales its Jacobian row in place (cameras: scales of the C kernel)
         for (int e = eb0 + tid; e < eb1; e += BM_T) {
@@ -1024,6 +1028,7 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
         }
         __syncthreads();   // rows of duplicate observations are read by other threads below
     }
+    PSTAMP(6);
     // ---- phase 2: K-columns of cameras that do not see a point stay zero (Yt / Wt are cleared once per solve)
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
         const int flag = A.odup[e];
@@ -1069,9 +1074,10 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
             }
         }
     }
+    PSTAMP(7);
+#undef PSTAMP
 }
 
-// blocks [0, cam_blocks): C role; blocks [cam_blocks, cam_blocks + point_blocks): P role
 constexpr int BM_WORK = BM_NW * 4 * 64;   // doubles of block-shared scratch: MFMA accumulators per wavefront / E^-1 of a block's points
 // C|P kernel. From the second iteration on every block first takes the accept/reject decision on the previous step itself
 // (same inputs, same arithmetic in every block; block 0 publishes the new state) — the state is double-buffered so nobody

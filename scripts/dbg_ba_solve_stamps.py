@@ -16,4 +16,6 @@ for nc, npts in ((5, 400), (10, 1000), (20, 1500)):
     d = [(int(st[16 + i]) - int(st0[16 + i])) / max(1, s.iterations) for i in range(5)]
     db = [(int(st[10 + i]) - int(st0[10 + i])) / max(1, s.iterations) for i in range(4)]
     print("   backsub kernel (block 0): phaseA=%d phaseB=%d phaseC=%d reduce=%d" % tuple(db))
+    dp = [(int(st[4 + i]) - int(st0[4 + i])) / max(1, s.iterations) for i in range(4)]
+    print("   point role (block 0): phase1=%d wait=%d rescale(first)=%d phase2=%d" % tuple(dp))
     print("nc", nc, "iterations", s.iterations, " ".join("%s=%d" % (n, v) for n, v in zip(names, d)), "cycles/iteration (100 MHz counter?)")
