@@ -9,7 +9,8 @@ struct BAArgs {
     // problem (device)
     double* cams; double* pts; const double* obs; const int* cam_idx; const int* pt_idx; const double* K;
     const int* pobs_start; const int* pobs_list; const int* cobs_start; const int* cobs_list;
-    const int* odup;   // per entry of pobs_list: 0 = only observation of its (point, camera), 1 = first of several, 2 = a later one
+    const int4* erec;  // per entry e of pobs_list: (observation index, camera, point, dup flag) in one 16-byte record; dup flag: 0 = only
+                       // observation of its (point, camera), 1 = first of several, 2 = a later one
     int nc, np, nobs, max_iterations;
     double huber;
     // workspaces (device)

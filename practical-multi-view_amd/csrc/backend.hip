@@ -78,7 +78,7 @@ int backend_create(pmv_ctx* c) {
     CKB(hipMalloc(&b->d_inliers, mt * 4)); CKB(hipMalloc(&b->d_info, 16));
     CKB(hipMalloc(&b->d_models, MAX_HYP * 6 * 8)); CKB(hipMalloc(&b->d_rt, 6 * 8)); CKB(hipMalloc(&b->d_Kp, 9 * 8));
     CKB(hipMalloc(&b->d_masks, (size_t)MAX_HYP * mt));
-    b->ba_io_bytes = (8 + nc * 6 + np * 3 + no * 2 + 10) * 8 + (no * 5 + np + nc + 8) * 4 + 64;
+    b->ba_io_bytes = (8 + nc * 6 + np * 3 + no * 2 + 10) * 8 + (no * 8 + np + nc + 8) * 4 + 128;
     CKB(hipMalloc(&b->d_ba_io, b->ba_io_bytes));
     b->pnp_in_bytes = PNP_HDR + mt * 20 + (size_t)MAX_HYP * 20 + 64;
     b->pnp_out_bytes = 48 + 16 + mt * 4 + 64;
@@ -266,8 +266,8 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     int* h_ci = (int*)(h_K + 10);
     int* h_pi = h_ci + n_obs;
     int* pstart = h_pi + n_obs; int* plist = pstart + (np + 1); int* cstart = plist + n_obs; int* clist = cstart + (nc + 1);
-    int* odup = clist + n_obs;
-    const size_t io_bytes = (size_t)((char*)(odup + n_obs) - hs);
+    int* odup = (int*)(((uintptr_t)(clist + n_obs) + 15) & ~(uintptr_t)15);   // 16-byte records (observation, camera, point, dup flag)
+    const size_t io_bytes = (size_t)((char*)(odup + (size_t)4 * n_obs) - hs);
     memcpy(h_cams, cams, (size_t)nc * 48); memcpy(h_pts, pts, (size_t)np * 24); memcpy(h_obs, obs_xy, (size_t)n_obs * 16);
     memcpy(h_K, K, 72); memcpy(h_ci, cam_idx, (size_t)n_obs * 4); memcpy(h_pi, pt_idx, (size_t)n_obs * 4);
     // observation lists per point / per camera (counting sort, observation order preserved)
@@ -290,7 +290,7 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
             bool earlier = false, later = false;
             for (int e2 = pstart[p]; e2 < e; e2++) earlier = earlier || cam_idx[plist[e2]] == c;
             for (int e2 = e + 1; e2 < pstart[p + 1]; e2++) later = later || cam_idx[plist[e2]] == c;
-            odup[e] = earlier ? 2 : (later ? 1 : 0);
+            odup[4 * e] = plist[e]; odup[4 * e + 1] = c; odup[4 * e + 2] = p; odup[4 * e + 3] = earlier ? 2 : (later ? 1 : 0);
         }
     }
     // launch mode: multi (one launch per LM phase, default) | single (one persistent workgroup); PMV_BA_MODE overrides
@@ -309,10 +309,10 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     int* d_ci = (int*)(d_K + 10);
     int* d_pi = d_ci + n_obs;
     int* d_pstart = d_pi + n_obs; int* d_plist = d_pstart + (np + 1); int* d_cstart = d_plist + n_obs; int* d_clist = d_cstart + (nc + 1);
-    int* d_odup = d_clist + n_obs;
+    const int4* d_erec = (const int4*)(dio + ((char*)odup - hs));
     BAArgs A;
     A.cams = d_cams; A.pts = d_pts; A.obs = d_obs; A.cam_idx = d_ci; A.pt_idx = d_pi; A.K = d_K;
-    A.pobs_start = d_pstart; A.pobs_list = d_plist; A.cobs_start = d_cstart; A.cobs_list = d_clist; A.odup = d_odup;
+    A.pobs_start = d_pstart; A.pobs_list = d_plist; A.cobs_start = d_cstart; A.cobs_list = d_clist; A.erec = d_erec;
     A.nc = nc; A.np = np; A.nobs = n_obs; A.max_iterations = max_iterations; A.huber = huber_delta;
     A.x = b->d_x; A.cand = b->d_cand; A.scale = b->d_scale; A.diag = b->d_diag; A.D2 = b->d_D2; A.step = b->d_step; A.res = b->d_res; A.J = b->d_J;
     A.Einv = b->d_Einv; A.gp = b->d_gp; A.Yd = b->d_Yd; A.Wd = b->d_Wd; A.S = b->d_S; A.rhs = b->d_rhs; A.Gpart = b->d_Gpart; A.summary = d_sum;

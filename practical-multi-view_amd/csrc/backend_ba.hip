@@ -1017,9 +1017,10 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
     const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
     if (st.first) {   // block-uniform: one thread per observation rescales its Jacobian row in place (cameras: scales of the C kernel)
         for (int e = eb0 + tid; e < eb1; e += BM_T) {
-            const int i = A.pobs_list[e];
-            const double* sc = A.scale + 6 * A.cam_idx[i];
-            const double* sp = sSp + (A.pt_idx[i] - p0) * 3;
+            const int4 rec = A.erec[e];
+            const int i = rec.x;
+            const double* sc = A.scale + 6 * rec.y;
+            const double* sp = sSp + (rec.z - p0) * 3;
             double* Jo = Jb + (size_t)i * 18;
 #pragma unroll
             for (int k = 0; k < 12; k++) Jo[k] *= sc[k % 6];
@@ -1031,10 +1032,10 @@ __device__ inline void bam_point_role(const BAArgs& A, const BAGState& st, int* 
     PSTAMP(6);
     // ---- phase 2: K-columns of cameras that do not see a point stay zero (Yt / Wt are cleared once per solve)
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
-        const int flag = A.odup[e];
+        const int4 rec = A.erec[e];   // (observation, camera, point, dup flag) in one load
+        const int flag = rec.w;
         if (flag == 2) continue;   // a later observation of the same (point, camera): folded into the first one
-        const int i = A.pobs_list[e];
-        const int c = A.cam_idx[i], pp = A.pt_idx[i];
+        const int i = rec.x, c = rec.y, pp = rec.z;
         const double* Jr = Jb + (size_t)i * 18;
         double jc[12], jp[6];
 #pragma unroll
@@ -1404,8 +1405,8 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
     const int eb0 = A.pobs_start[p0], eb1 = A.pobs_start[p1];
     double mc = 0, cc = 0, dn2 = 0, xn2 = 0;
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
-        const int i = A.pobs_list[e];
-        const int c = A.cam_idx[i];
+        const int4 rec = A.erec[e];
+        const int i = rec.x, c = rec.y;
         const double* Jr = Jb + (size_t)i * 18;
         double jy0 = 0, jy1 = 0;   // y_c = -step_c
 #pragma unroll
@@ -1439,8 +1440,8 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
     __syncthreads();
     BSTAMP(11);
     for (int e = eb0 + tid; e < eb1; e += BM_T) {
-        const int i = A.pobs_list[e];
-        const int c = A.cam_idx[i], pl = A.pt_idx[i] - p0;
+        const int4 rec = A.erec[e];
+        const int i = rec.x, c = rec.y, pl = rec.z - p0;
         const double* Jr = Jb + (size_t)i * 18;
         double sc[6], sp[3], xp[3];
 #pragma unroll
