@@ -251,7 +251,11 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     REQ(ctx && cams && pts && obs_xy && cam_idx && pt_idx && K, PMV_ERR_INVALID, "pmv_ba_solve: null argument");
     REQ(nc >= 1 && nc <= ctx->max_ba_cams && np >= 1 && np <= ctx->max_ba_points && n_obs >= 1 && n_obs <= ctx->max_ba_obs, PMV_ERR_CAPACITY,
         "pmv_ba_solve: nc=%d np=%d n_obs=%d exceed capacity %d/%d/%d", nc, np, n_obs, ctx->max_ba_cams, ctx->max_ba_points, ctx->max_ba_obs);
-    REQ(max_iterations >= 1 && max_iterations <= BA_MAX_ITERATIONS && huber_delta > 0, PMV_ERR_INVALID, "pmv_ba_solve: bad options");
+    REQ(max_iterations >= 0 && max_iterations <= BA_MAX_ITERATIONS && huber_delta > 0, PMV_ERR_INVALID, "pmv_ba_solve: bad options");
+    if (max_iterations == 0) {   // ceres::Solve with max_num_iterations = 0 leaves the parameters untouched (costs are not evaluated here)
+        if (summary) { summary->initial_cost = summary->final_cost = 0.0; summary->iterations = 0; summary->successful_steps = 0; summary->termination = 0; }
+        return PMV_OK;
+    }
     tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     BackendBuffers* b = ctx->be;

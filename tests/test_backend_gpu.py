@@ -151,8 +151,10 @@ def test_ba_duplicate_point_camera_observations(gpu_ctx_factory):
 def test_backend_argument_errors(pmv, gpu_ctx_factory):
     ctx = gpu_ctx_factory(64, 64, n_slots=1, max_tracks=128, max_ba_cams=4, max_ba_points=64, max_ba_obs=256)
     P = scenes.ba_problem(2, nc=3, npts=40)
-    with pytest.raises(pmv.PmvError) as e:     # LM iteration count must be 1..512
-        ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 0)
+    c0, p0, s0 = ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 0)   # 0 iterations: untouched
+    assert np.array_equal(c0, P["cams"]) and np.array_equal(p0, P["pts"]) and s0.iterations == 0
+    with pytest.raises(pmv.PmvError) as e:     # LM iteration count must be 0..512
+        ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 513)
     assert e.value.code == -2
     with pytest.raises(pmv.PmvError) as e:     # more cameras than the context was created for
         Q = scenes.ba_problem(2, nc=5, npts=40)
