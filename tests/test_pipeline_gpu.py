@@ -123,3 +123,18 @@ def test_metric_config_full_sequence(pmv, gpu_ctx_factory):
     travelled = np.linalg.norm(o.poses[:, 9:12], axis=1)
     dt = np.linalg.norm(g.poses[:, 9:12] - o.poses[:, 9:12], axis=1)
     assert (dt <= 0.02 * travelled + 0.05).all(), f"trajectories drift apart: {dt.max()}"
+
+
+def test_result_lifetime_variants(pmv, gpu_ctx_factory):
+    """Native results can be freed at once, later (defer_free) or on a background thread (async_free + drain): same numbers."""
+    cfg, n = K07, 20
+    frames, poses = pmv.synth_sequence(1003, 0, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"])
+    K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096)
+    ctx.frames_stage(0, frames)
+    a = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1, n_threads=4)
+    b = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1, n_threads=1, defer_free=True)
+    c = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=0, async_free=True)
+    assert np.array_equal(a.poses, b.poses) and np.array_equal(a.poses, c.poses)
+    b.free(); b.free()          # idempotent
+    ctx.pipeline_drain()
