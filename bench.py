@@ -44,6 +44,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # one rank per GPU: N > 1 must be started through torch.distributed.run (nothing is re-exec'ed from here)
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`\n")
+        sys.exit(2)
     dist = None
     torch = None
     if world > 1:

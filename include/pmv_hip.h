@@ -67,10 +67,14 @@ int pmv_frame_num_levels(pmv_ctx* ctx, int slot); /* maxLevel actually built (>=
 /* ---- feature extraction ------------------------------------------------------------------------ */
 /* cells: n_cells * 4 ints (x0, y0, w, h), each <= 255x255, sub-views of the frame in `slot`.
  * out_xy: n_cells * max_per_cell * 2 ints, CELL-LOCAL (x, y) in descending-response order as OpenCV returns them;
- * out_count: n_cells ints. */
+ * out_count: n_cells ints. max_per_cell <= 0 means "no limit" as in cv::goodFeaturesToTrack: out_xy must then hold
+ * n_cells * PMV_GFTT_UNLIMITED_CAP * 2 ints (cell stride PMV_GFTT_UNLIMITED_CAP corners); a cell with more corners than that
+ * returns PMV_ERR_OVERFLOW. Status bits of one call never leak into the next. */
+#define PMV_GFTT_UNLIMITED_CAP 4096
 int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
                     double min_dist, int* out_xy, int* out_count);
-/* Same geometry; out_score: n_cells * max_per_cell doubles (the reference fills Feature::score). */
+/* Same geometry; out_score: n_cells * max_per_cell doubles (the reference fills Feature::score). max_per_cell <= 0 returns no
+ * features (ShiTomasiFeatureExtractor.cpp:37-44). */
 int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
                          int* out_xy, double* out_score, int* out_count);
 /* Debug/parity: response map of one cell (GFTT: float32 min-eigenvalue map before thresholding). */
@@ -142,7 +146,7 @@ typedef struct pmv_pipeline_params {
     int min_tracked_features, tracked_features_tol, init_frames, bundle_size, ba_iterations;
     int extractor;      /* 0 = goodFeaturesToTrack (reference default), 1 = ShiTomasi */
     int threaded;       /* 0 = sequential schedule, 1 = front-end / back-end host threads (the reference's two threads) */
-    int n_threads;      /* unused by the HIP path */
+    int n_threads;      /* host threads that evaluate the triangulator's five-point RANSAC hypotheses side by side (>= 1; results do not depend on it) */
     int build_pyramids; /* rebuild the pyramids of slots 0..n_frames-1 inside the call */
 } pmv_pipeline_params;
 typedef struct pmv_pipeline_result pmv_pipeline_result;
@@ -158,7 +162,14 @@ void pmv_pipeline_get_poses(const pmv_pipeline_result* r, double* out12); /* per
 int pmv_pipeline_num_frames(const pmv_pipeline_result* r);
 int pmv_pipeline_frame_feature_count(const pmv_pipeline_result* r, int k);
 void pmv_pipeline_get_frame_features(const pmv_pipeline_result* r, int k, int* out3); /* (column,row,landmark id|-1) */
-void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out16);
+/* Run statistics: pmv_pipeline_stats_count() (= 24) doubles, in this order:
+ *   [0] lk_calls [1] lk_points [2] detect_calls [3] pnp_calls [4] pnp_points [5] tri_calls [6] ba_calls [7] ba_obs [8] ba_points
+ *   [9] heuristic_motion (frames whose pose came from motionHeuristics' fallback branch) [10] run seconds [11] init_offset
+ *   [12] live landmarks at the end [13] scale; wall seconds per stage as seen by the calling host threads: [14] t_lk [15] t_detect
+ *   [16] t_pnp [17] t_tri [18] t_ba [19] t_pnp_kernel [20] t_ba_kernel [21] t_tri_essential [22] t_tri_pose; [23] five-point
+ *   RANSAC samples drawn. The caller's buffer must hold pmv_pipeline_stats_count() doubles. */
+int pmv_pipeline_stats_count(void);
+void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out24);
 
 #ifdef __cplusplus
 }

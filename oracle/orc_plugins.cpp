@@ -14,7 +14,7 @@ using namespace vo;
 struct CpuGftt : GoodFeatureExtractorBase {
     void gftt(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out) override {
         out.clear();
-        std::vector<int> xy((size_t)std::max(max, 1) * 2);
+        std::vector<int> xy((size_t)(max > 0 ? max : 65536) * 2);   // max <= 0: no limit (at most one corner per pixel of a 255x255 cell)
         for (auto& c : cells) {
             const int n = orc::gftt_cell(c.host, c.full_w, c.full_h, c.x0, c.y0, c.w, c.h, max, quality, min_distance, xy.data(), nullptr);
             std::vector<std::pair<int, int>> v;
@@ -90,7 +90,8 @@ void orc_pipeline_get_poses(void* h, double* out) { vo::pipeline_get_poses(*(vo:
 int orc_pipeline_num_frames(void* h) { return vo::pipeline_num_frames(*(vo::PipelineRun*)h); }
 int orc_pipeline_frame_feature_count(void* h, int k) { return vo::pipeline_frame_feature_count(*(vo::PipelineRun*)h, k); }
 void orc_pipeline_get_frame_features(void* h, int k, int* out) { vo::pipeline_get_frame_features(*(vo::PipelineRun*)h, k, out); }
-void orc_pipeline_get_stats(void* h, double* out16) { vo::pipeline_get_stats(*(vo::PipelineRun*)h, out16); }
+int orc_pipeline_stats_count(void) { return vo::PIPELINE_STATS_COUNT; }
+void orc_pipeline_get_stats(void* h, double* out24) { vo::pipeline_get_stats(*(vo::PipelineRun*)h, out24); }
 }
 
 // ---- host-logic probes for the CPU test-suite (KA5/KA6/KA9/KA10 of SURVEY.md §8c) ------------------------------------------

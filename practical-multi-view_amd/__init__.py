@@ -39,8 +39,11 @@ ABI_SYMBOLS = [
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates",
     "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_prof_kernel_name", "pmv_prof_read",
     "pmv_pipeline_run", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
-    "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_get_stats",
+    "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_stats_count", "pmv_pipeline_get_stats",
 ]
+
+
+GFTT_UNLIMITED_CAP = 4096   # PMV_GFTT_UNLIMITED_CAP of include/pmv_hip.h
 
 
 class PipelineParams(C.Structure):
@@ -71,7 +74,8 @@ class PipelineResult:
                 if c:
                     lib.pmv_pipeline_get_frame_features(handle, k, _p(a, _i32p))
                 self.features.append(a)
-        st = np.zeros(24, np.float64)
+        st = np.zeros(lib.pmv_pipeline_stats_count(), np.float64)   # the library says how many doubles it writes
+        assert len(st) >= len(STAT_KEYS)
         lib.pmv_pipeline_get_stats(handle, _p(st, _f64p))
         self.stats = dict(zip(STAT_KEYS, [float(v) for v in st[:len(STAT_KEYS)]]))
         self._deferred = None   # (lib, handle) when the caller asked to free the native result later (defer_free)
@@ -211,7 +215,8 @@ class Context:
     def detect_gftt(self, slot, cells, max_per_cell, quality=0.01, min_dist=5.0):
         cells = np.ascontiguousarray(cells, np.int32).reshape(-1, 4)
         n = cells.shape[0]
-        xy = np.zeros((n, max_per_cell, 2), np.int32)
+        cap = max_per_cell if max_per_cell > 0 else GFTT_UNLIMITED_CAP   # max_per_cell <= 0: no limit (cv::goodFeaturesToTrack)
+        xy = np.zeros((n, cap, 2), np.int32)
         cnt = np.zeros(n, np.int32)
         self._ck(self.lib.pmv_detect_gftt(self.h, slot, _p(cells, _i32p), n, max_per_cell, C.c_double(quality),
                                           C.c_double(min_dist), _p(xy, _i32p), _p(cnt, _i32p)))
@@ -220,8 +225,8 @@ class Context:
     def detect_shitomasi(self, slot, cells, max_per_cell, quality=0.4):
         cells = np.ascontiguousarray(cells, np.int32).reshape(-1, 4)
         n = cells.shape[0]
-        xy = np.zeros((n, max_per_cell, 2), np.int32)
-        sc = np.zeros((n, max_per_cell), np.float64)
+        xy = np.zeros((n, max(max_per_cell, 1), 2), np.int32)
+        sc = np.zeros((n, max(max_per_cell, 1)), np.float64)
         cnt = np.zeros(n, np.int32)
         self._ck(self.lib.pmv_detect_shitomasi(self.h, slot, _p(cells, _i32p), n, max_per_cell, C.c_double(quality),
                                                _p(xy, _i32p), _p(sc, _f64p), _p(cnt, _i32p)))

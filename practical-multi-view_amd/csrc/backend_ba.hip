@@ -1545,12 +1545,6 @@ hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double
     double* tmp3 = candrot + 16 * A.nc;         // nobs * 3
     const size_t shm = ((size_t)(m + 1) * m + (size_t)m) * sizeof(double);
     if (A.max_iterations > BA_MAX_ITERATIONS) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_bam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     ProfScope ps(K_BA_LM, s);
     const int tiles = A.tiles_r * A.tiles_c;
     // launches: E0 (+ the clear of Yt | Wt), then per iteration C|P (with the decision on the previous step) -> G -> S -> B, then F
@@ -1583,15 +1577,16 @@ hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* 
 hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A) {
     const int m = 6 * A.nc;
     const size_t shm = ((size_t)(m + 1) * m + (size_t)m) * sizeof(double);   // [S | rhs row] + camera step, LDS-resident
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     ProfScope ps(K_BA_LM, s);
     hipLaunchKernelGGL(k_ba_lm, dim3(1), dim3(BA_T), shm, s, A);
     return hipGetLastError();
+}
+
+// LDS opt-in (150 KB reduced camera system) per device; see frontend_prepare_device()
+hipError_t backend_prepare_device() {
+    hipError_t e = hipFuncSetAttribute((const void*)k_bam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }
 
 }  // namespace pmv

@@ -70,6 +70,8 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     for (auto& l : c->slot_layout) l.n_levels = 0;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(nullptr, "%s: %s", #x, hipGetErrorString(e_)); pmv_ctx_destroy(c); return PMV_ERR_HIP; } } while (0)
     CK(hipSetDevice(device));
+    CK(frontend_prepare_device());
+    CK(backend_prepare_device());
     CK(hipStreamCreateWithFlags(&c->s_front, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&c->s_back, hipStreamNonBlocking));
     CK(hipMalloc(&c->d_slots, (size_t)c->cap.slot_bytes * n_slots));
@@ -265,7 +267,7 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     return PMV_OK;
 }
 
-static int check_cells(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell) {
+static int check_cells(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell) {   // max_per_cell: already >= 1
     REQ(ctx && cells, PMV_ERR_INVALID, "detect: null argument");
     REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "detect: slot out of range");
     REQ(n_cells >= 1 && n_cells <= MAX_CELLS, PMV_ERR_CAPACITY, "detect: n_cells=%d (max %d)", n_cells, MAX_CELLS);
@@ -282,6 +284,10 @@ static int check_cells(pmv_ctx* ctx, int slot, const int* cells, int n_cells, in
 
 int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
                     double min_dist, int* out_xy, int* out_count) {
+    // cv::goodFeaturesToTrack: maxCorners <= 0 means "no limit" (the reference gets there when min_tracked_features < number of
+    // grid cells, OdometryPipeline.cpp:438 integer division). The caller's out_xy then holds PMV_GFTT_UNLIMITED_CAP corners per cell.
+    const int unlimited = max_per_cell <= 0;
+    if (unlimited) max_per_cell = MAX_PER_CELL;
     int rc = check_cells(ctx, slot, cells, n_cells, max_per_cell);
     if (rc) return rc;
     REQ(out_xy && out_count, PMV_ERR_INVALID, "pmv_detect_gftt: null output");
@@ -289,14 +295,16 @@ int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int m
     CKC(hipSetDevice(ctx->device));
     const PyrLayout& L = ctx->slot_layout[slot];
     CKC(hipMemcpyAsync(ctx->d_cells, cells, (size_t)n_cells * 16, hipMemcpyHostToDevice, ctx->s_front));
+    CKC(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->s_front));   // overflow bits are per call: one overflow must not poison later calls
     CKC(launch_gftt(ctx->s_front, ctx->d_slots + (size_t)slot * L.slot_bytes, L, ctx->d_cells, n_cells, max_per_cell, quality,
-                    min_dist, (float*)ctx->d_eig, (unsigned*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_count, ctx->d_flags));
+                    min_dist, unlimited, (float*)ctx->d_eig, (unsigned*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_count, ctx->d_flags));
     const size_t nxy = (size_t)n_cells * max_per_cell * 8;
     CKC(hipMemcpyAsync(ctx->h_det_xy, ctx->d_det_xy, nxy, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipMemcpyAsync(ctx->h_det_count, ctx->d_det_count, (size_t)n_cells * 4, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipMemcpyAsync(ctx->h_det_count + MAX_CELLS, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipStreamSynchronize(ctx->s_front));
     REQ((ctx->h_det_count[MAX_CELLS] & 1) == 0, PMV_ERR_OVERFLOW, "pmv_detect_gftt: candidate list overflow");
+    REQ((ctx->h_det_count[MAX_CELLS] & 4) == 0, PMV_ERR_OVERFLOW, "pmv_detect_gftt: more than %d corners in a cell with max_per_cell <= 0 (no limit)", MAX_PER_CELL);
     memcpy(out_xy, ctx->h_det_xy, nxy);
     memcpy(out_count, ctx->h_det_count, (size_t)n_cells * 4);
     return PMV_OK;
@@ -304,6 +312,11 @@ int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int m
 
 int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
                          int* out_xy, double* out_score, int* out_count) {
+    if (max_per_cell <= 0) {   // ShiTomasiFeatureExtractor.cpp:37-44: `if (i >= max) break` before the first feature -> nothing
+        REQ(ctx && cells && out_count && n_cells >= 1 && n_cells <= MAX_CELLS, PMV_ERR_INVALID, "pmv_detect_shitomasi: bad argument");
+        for (int i = 0; i < n_cells; i++) out_count[i] = 0;
+        return PMV_OK;
+    }
     int rc = check_cells(ctx, slot, cells, n_cells, max_per_cell);
     if (rc) return rc;
     REQ(out_xy && out_score && out_count, PMV_ERR_INVALID, "pmv_detect_shitomasi: null output");
@@ -311,6 +324,7 @@ int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, 
     CKC(hipSetDevice(ctx->device));
     const PyrLayout& L = ctx->slot_layout[slot];
     CKC(hipMemcpyAsync(ctx->d_cells, cells, (size_t)n_cells * 16, hipMemcpyHostToDevice, ctx->s_front));
+    CKC(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->s_front));
     CKC(launch_shitomasi(ctx->s_front, ctx->d_slots + (size_t)slot * L.slot_bytes, L, ctx->d_cells, n_cells, max_per_cell, quality,
                          ctx->d_eig, (unsigned long long*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_score, ctx->d_det_count, ctx->d_flags));
     const size_t nxy = (size_t)n_cells * max_per_cell * 8;

@@ -60,12 +60,14 @@ __global__ __launch_bounds__(256) void k_pyrdown(uint8_t* slots, PyrLayout L, in
 }
 
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n) {
+    if (!slots || n < 1 || first_slot < 0 || L.n_levels < 1) return hipErrorInvalidValue;
     dim3 grid((L.w[0] + 2 * PAD + 1023) / 1024, L.h[0] + 2 * PAD, n);
     ProfScope ps(K_PAD0, s);
     hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, s, slots, L, first_slot);
     return hipGetLastError();
 }
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int ld, int first_slot, int n) {
+    if (!slots || n < 1 || first_slot < 0 || ld < 1 || ld >= L.n_levels) return hipErrorInvalidValue;
     dim3 grid((L.w[ld] + 2 * PAD + 1023) / 1024, L.h[ld] + 2 * PAD, n);
     ProfScope ps(K_PYRDOWN, s);
     hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, slots, L, ld, first_slot);
@@ -332,6 +334,8 @@ hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* nex
                      const float* d_prev_xy, const int* d_order, int n_blocks, int n, const LKParams& P, float* d_out_xy,
                      uint8_t* d_status, float* d_err) {
     if (n <= 0) return hipSuccess;
+    // every pointer the kernel dereferences: a null base must come back as an error code, never reach a launch
+    if (!prev_slot || !next_slot || !d_prev_xy || !d_order || !d_out_xy || !d_status || !d_err || n_blocks < n || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     ProfScope ps(K_LK, s);
     hipLaunchKernelGGL(k_lk, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
     return hipGetLastError();
@@ -420,9 +424,10 @@ __global__ __launch_bounds__(256) void k_gftt_eig(const uint8_t* __restrict__ sl
 // closer than minDistance" is evaluated as: repeat {arg-max over live candidates; accept; kill every candidate closer
 // than minDistance} — identical result, max_corners rounds, no sort.
 constexpr int GFTT_CAP = 16384;
+constexpr size_t GFTT_SELECT_SHM = GFTT_CAP * 8 + 16 * 8 + 16;
 __global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ cells, const float* __restrict__ eig,
                                                       const unsigned* __restrict__ cellmax, int max_corners,
-                                                      double quality, double min_dist, int* __restrict__ out_xy,
+                                                      double quality, double min_dist, int unlimited, int* __restrict__ out_xy,
                                                       int* __restrict__ out_count, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* cval = (float*)smem;                       // GFTT_CAP
@@ -497,26 +502,28 @@ __global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ ce
         }
         __syncthreads();
     }
+    // cv::goodFeaturesToTrack(maxCorners <= 0) has no limit; here the caller's buffer holds max_corners: more corners than that
+    // is reported (bit 2), not silently truncated
+    if (unlimited && naccepted == max_corners) {
+        int live = 0;
+        for (int i = tid; i < ncand; i += 1024) live |= cval[i] > 0.f;
+        if (live) atomicOr(flags, 4);
+    }
     if (tid == 0) out_count[cell] = naccepted;
 }
 
 hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
-                       int max_per_cell, double quality, double min_dist, float* d_eig, unsigned* d_cellmax,
+                       int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,
                        int* d_out_xy, int* d_out_count, int* d_flags) {
+    if (!slot || !d_cells || !d_eig || !d_cellmax || !d_out_xy || !d_out_count || !d_flags || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned) * n_cells, s);
     if (e != hipSuccess) return e;
     { ProfScope ps(K_GFTT_EIG, s);
     hipLaunchKernelGGL(k_gftt_eig, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_eig, d_cellmax); }
     ProfScope ps2(K_GFTT_SELECT, s);
-    const size_t shm = GFTT_CAP * 8 + 16 * 8 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute((const void*)k_gftt_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    const size_t shm = GFTT_SELECT_SHM;   // opt-in above 64 KB: frontend_prepare_device(), once per context on its device
     hipLaunchKernelGGL(k_gftt_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_eig, d_cellmax, max_per_cell,
-                       quality, min_dist, d_out_xy, d_out_count, d_flags);
+                       quality, min_dist, unlimited, d_out_xy, d_out_count, d_flags);
     return hipGetLastError();
 }
 
@@ -583,6 +590,7 @@ __global__ __launch_bounds__(256) void k_st_resp(const uint8_t* __restrict__ slo
 }
 
 constexpr int ST_CAP = 8192;
+constexpr size_t ST_SELECT_SHM = ST_CAP * 12 + 16 * 12 + 16;
 __global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cells, const double* __restrict__ resp,
                                                     const unsigned long long* __restrict__ cellmax, int max_feats,
                                                     double quality, int* __restrict__ out_xy,
@@ -650,21 +658,24 @@ __global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cell
 hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
                             int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,
                             int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags) {
+    if (!slot || !d_cells || !d_resp || !d_cellmax || !d_out_xy || !d_out_score || !d_out_count || !d_flags || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned long long) * n_cells, s);
     if (e != hipSuccess) return e;
     { ProfScope ps(K_ST_RESP, s);
     hipLaunchKernelGGL(k_st_resp, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_resp, d_cellmax); }
     ProfScope ps2(K_ST_SELECT, s);
-    const size_t shm = ST_CAP * 12 + 16 * 12 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute((const void*)k_st_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    const size_t shm = ST_SELECT_SHM;
     hipLaunchKernelGGL(k_st_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_resp, d_cellmax, max_per_cell,
                        quality, d_out_xy, d_out_score, d_out_count, d_flags);
     return hipGetLastError();
+}
+
+// Kernels that need more than the default 64 KB of dynamic LDS opt in per DEVICE (function attributes are per device in HIP):
+// called by pmv_ctx_create after hipSetDevice, so a second context on another GPU of the same process is set up as well.
+hipError_t frontend_prepare_device() {
+    hipError_t e = hipFuncSetAttribute((const void*)k_gftt_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GFTT_SELECT_SHM);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_st_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_SELECT_SHM);
 }
 
 }  // namespace pmv

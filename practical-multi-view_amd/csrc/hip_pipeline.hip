@@ -25,13 +25,14 @@ struct HipGftt : GoodFeatureExtractorBase {
     std::vector<int> rect, xy, cnt;
     void gftt(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out) override {
         out.assign(cells.size(), {});
-        if (cells.empty() || max < 1) return;
+        if (cells.empty()) return;
         cells_of(cells, rect);
-        xy.resize(cells.size() * (size_t)max * 2);
+        const size_t cap = max > 0 ? (size_t)max : (size_t)PMV_GFTT_UNLIMITED_CAP;   // max <= 0: no limit (cv::goodFeaturesToTrack)
+        xy.resize(cells.size() * cap * 2);
         cnt.resize(cells.size());
         ck(ctx, pmv_detect_gftt(ctx, cells[0].slot, rect.data(), (int)cells.size(), max, quality, min_distance, xy.data(), cnt.data()));
         for (size_t c = 0; c < cells.size(); c++)
-            for (int i = 0; i < cnt[c]; i++) out[c].push_back({xy[(c * max + i) * 2], xy[(c * max + i) * 2 + 1]});
+            for (int i = 0; i < cnt[c]; i++) out[c].push_back({xy[(c * cap + i) * 2], xy[(c * cap + i) * 2 + 1]});
     }
 };
 struct HipShiTomasi : ShiTomasiExtractorBase {
@@ -107,7 +108,10 @@ int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K
     auto* res = new pmv_pipeline_result();
     vo::PipelineRun& run = res->run;
     vo::PipelineParams vp;
-    memcpy(&vp, P, sizeof(vp));   // identical leading layout; the last int is build_pyramids here
+    vp.n_frames = P->n_frames; vp.w = P->w; vp.h = P->h;
+    vp.min_tracked_features = P->min_tracked_features; vp.tracked_features_tol = P->tracked_features_tol;
+    vp.init_frames = P->init_frames; vp.bundle_size = P->bundle_size; vp.ba_iterations = P->ba_iterations;
+    vp.extractor = P->extractor; vp.threaded = P->threaded; vp.n_threads = P->n_threads; vp.reserved = 0;
     try {
         if (P->build_pyramids) ck(ctx, pmv_frames_build(ctx, 0, P->n_frames));
         vo::pipeline_setup(run, vp, nullptr, K9, gt_poses12);
@@ -155,5 +159,6 @@ void pmv_pipeline_get_poses(const pmv_pipeline_result* r, double* out) { vo::pip
 int pmv_pipeline_num_frames(const pmv_pipeline_result* r) { return vo::pipeline_num_frames(r->run); }
 int pmv_pipeline_frame_feature_count(const pmv_pipeline_result* r, int k) { return vo::pipeline_frame_feature_count(r->run, k); }
 void pmv_pipeline_get_frame_features(const pmv_pipeline_result* r, int k, int* out) { vo::pipeline_get_frame_features(r->run, k, out); }
-void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out16) { vo::pipeline_get_stats(r->run, out16); }
+int pmv_pipeline_stats_count(void) { return vo::PIPELINE_STATS_COUNT; }
+void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out24) { vo::pipeline_get_stats(r->run, out24); }
 }

@@ -7,7 +7,7 @@
 
 namespace pmv {
 constexpr int MAX_CELLS = 64;       // 1920x1080 -> 8x5 = 40 cells of 255x255
-constexpr int MAX_PER_CELL = 512;
+constexpr int MAX_PER_CELL = 4096;    // also the capacity of an "unlimited" (max_per_cell <= 0) goodFeaturesToTrack call
 struct BackendBuffers;              // PnP / BA device workspaces (backend.hip)
 }
 
@@ -44,4 +44,6 @@ void set_err(pmv_ctx* c, const char* fmt, ...);
 PyrLayout make_layout(int w, int h);
 int backend_create(pmv_ctx* c);     // allocates PnP/BA workspaces
 void backend_destroy(pmv_ctx* c);
+hipError_t frontend_prepare_device();   // per-device kernel attributes (LDS opt-in), called with the context's device current
+hipError_t backend_prepare_device();
 }

@@ -109,7 +109,7 @@ hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* nex
 
 // GFTT: eig maps (n_cells * 255*255 floats), cell max (n_cells uint32 ordered keys), outputs
 hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
-                       int max_per_cell, double quality, double min_dist, float* d_eig, unsigned* d_cellmax,
+                       int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,
                        int* d_out_xy, int* d_out_count, int* d_flags);
 hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
                             int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,

@@ -18,18 +18,20 @@ inline const char* kernel_name(int id) {
 // "ba_lm_chain" times one whole LM solve: the chain of k_bam_* launches (or k_ba_lm in single-workgroup mode); every other
 // class is exactly one kernel per launch.
 struct Profiler {
-    static constexpr int CAP = 8192;   // launches per kernel class between resets
+    static constexpr int CHUNK = 8192;       // the event pool of a class grows by this many launches at a time ...
+    static constexpr int CAP = 1 << 20;      // ... up to this many launches between resets (beyond it: counted in `dropped`)
     bool enabled = false;
     unsigned mask = ~0u;               // kernel classes that are recorded while enabled (bit = KernelId)
     std::vector<hipEvent_t> ev[K_COUNT];
     int used[K_COUNT] = {0};
     long dropped[K_COUNT] = {0};
     hipEvent_t* next(int id) {
-        if (ev[id].empty()) {
-            ev[id].resize(2 * CAP);
-            for (auto& e : ev[id]) (void)hipEventCreate(&e);
-        }
         if (used[id] + 2 > 2 * CAP) { dropped[id]++; return nullptr; }
+        if (used[id] + 2 > (int)ev[id].size()) {
+            const size_t old = ev[id].size();
+            ev[id].resize(old + 2 * CHUNK);
+            for (size_t i = old; i < ev[id].size(); i++) (void)hipEventCreate(&ev[id][i]);
+        }
         hipEvent_t* p = &ev[id][used[id]];
         used[id] += 2;
         return p;

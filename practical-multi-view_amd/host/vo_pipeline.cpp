@@ -179,9 +179,14 @@ void BundleAdjustmentBase::apply(Frame& f) {
     std::vector<std::shared_ptr<Feature3D>> p3d_ptr;
     std::vector<double> p3d_opt;
     HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[2]);
+    std::vector<std::shared_ptr<Frame>> window((size_t)n);   // snapshot under the lock: the front-end thread may be appending
+    {
+        std::lock_guard<std::mutex> lk(tracker->frames_mu);
+        for (int i = fn - n; i < fn; i++) window[(size_t)(i - (fn - n))] = tracker->frames[i];
+    }
     for (int i = fn - n; i < fn; i++) {
         if (i == 0) continue;
-        std::shared_ptr<Frame> frame = tracker->frames[i];
+        const std::shared_ptr<Frame>& frame = window[(size_t)(i - (fn - n))];
         double rod[3];
         Mat3 Rt = tracker->R[i].t();
         rodrigues_m2v(Rt.m, rod);
@@ -404,8 +409,9 @@ void OdometryPipeline::run_threaded() {
     R.push_back(Mat3::eye()); t.push_back(Vec3{{0, 0, 0}});
     R_s.push_back(Mat3::eye()); t_s.push_back(Vec3{{0, 0, 0}});
     // job pipe (dlib::pipe<Job> in the reference). `frames` only grows at the back (front-end) while the back-end touches
-    // entries j, j+1 <= k-1 that the front-end no longer reads; the vector itself is guarded by a mutex.
-    std::mutex mu;
+    // entries j, j+1 <= k-1 that the front-end no longer reads; the vector itself is guarded by frames_mu, which
+    // BundleAdjustmentBase::apply takes as well when it snapshots its window.
+    std::mutex& mu = frames_mu;
     std::condition_variable cv;
     std::deque<int> jobs;
     bool done = false;
@@ -431,7 +437,7 @@ void OdometryPipeline::run_threaded() {
         Frame frame(images[i]);
         if (frame.isEmpty()) continue;
         {
-            // addFrame reads frames[k-1] and appends frames[k]; BA reads tracker->frames[i] under the same lock domain
+            // addFrame reads frames[k-1] and appends frames[k]; BA snapshots tracker->frames[i] under the same mutex
             std::unique_lock<std::mutex> lk(mu);
             frame.frame = (int)frames.size();
         }

@@ -10,6 +10,7 @@
 #include <functional>
 #include <chrono>
 #include <list>
+#include <mutex>
 
 namespace vo {
 
@@ -131,6 +132,10 @@ public:
     // a std::list with the node iterator stored in the landmark has the same content/order semantics at O(1) per erase
     std::list<std::shared_ptr<Feature3D>> feats3d;
     std::vector<std::shared_ptr<Frame>> frames;
+    // guards the `frames` VECTOR (push_back by the front-end thread, element reads by the back-end thread: estimatePose's job
+    // hand-over and BundleAdjustmentBase::apply's window). The Frame objects themselves are never touched by both threads at
+    // once. frame_mutex of the reference (OdometryPipeline.h) plays the same role.
+    std::mutex frames_mu;
     std::vector<Mat3> R, R_s;
     std::vector<Vec3> t, t_s;
     BaseFeatureExtractor* extractor = nullptr;

@@ -52,7 +52,7 @@ class Oracle:
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
         x0, y0, cw, ch = [int(v) for v in cell]
-        xy = np.zeros((max(max_corners, 1), 2), np.int32)
+        xy = np.zeros((max_corners if max_corners > 0 else 65536, 2), np.int32)   # max_corners <= 0: no limit
         eig = np.zeros((ch, cw), np.float32)
         n = self.lib.orc_gftt_cell(_p(img, _u8p), w, h, x0, y0, cw, ch, max_corners, C.c_double(quality),
                                    C.c_double(min_dist), _p(xy, _i32p), _p(eig, _f32p))
@@ -107,7 +107,7 @@ class PipelineResult:
             if c:
                 g("get_frame_features")(handle, k, _p(a, _i32p))
             self.features.append(a)
-        st = np.zeros(24, np.float64)
+        st = np.zeros(g("stats_count")(), np.float64)
         g("get_stats")(handle, _p(st, _f64p))
         keys = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
                 "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale", "t_lk", "t_detect", "t_pnp", "t_tri",

@@ -47,3 +47,31 @@ def test_oracle_library_loads(orc):
     for sym in ("orc_pyr_down", "orc_scharr", "orc_lk_track", "orc_gftt_cell", "orc_shitomasi_cell", "orc_ba_residuals", "orc_ba_solve",
                 "orc_pnp_ransac", "orc_pipeline_run"):
         assert hasattr(orc.lib, sym)
+
+
+def test_stats_buffer_size_matches_header_and_binding(pmv):
+    """pmv_pipeline_get_stats writes pmv_pipeline_stats_count() doubles: the header documents that number and every field,
+    the Python binding names every field (a C caller that sizes its buffer from the header must not be overrun)."""
+    lib = pmv.load_library()
+    n = lib.pmv_pipeline_stats_count()
+    src = open(os.path.join(ROOT, "include", "pmv_hip.h")).read()
+    doc = src[src.index("Run statistics"):src.index("int pmv_pipeline_stats_count")]
+    assert f"(= {n})" in doc
+    fields = [int(k) for k in re.findall(r"\[(\d+)\]", doc)]
+    assert fields == list(range(n)), "the header must document every statistics slot exactly once, in order"
+    assert len(pmv.STAT_KEYS) == n
+    assert re.search(r"pmv_pipeline_get_stats\([^)]*double\* out%d\)" % n, src)
+    # the oracle's twin reports the same count (same host code)
+    import orc_binding
+    assert orc_binding.load().lib.orc_pipeline_stats_count() == n
+
+
+def test_pipeline_params_layout_matches_header(pmv):
+    """ctypes mirror of pmv_pipeline_params: same field names in the same order as the header"""
+    src = open(os.path.join(ROOT, "include", "pmv_hip.h")).read()
+    body = src[src.index("typedef struct pmv_pipeline_params {"):src.index("} pmv_pipeline_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"int ([^;]+);", body):
+        names += [n.strip() for n in decl.split(",")]
+    assert names == [f[0] for f in pmv.PipelineParams._fields_]

@@ -78,6 +78,55 @@ def test_gftt_edge_cases(pmv, orc, gpu_ctx_factory):
         assert np.array_equal(g, orc.gftt_cell(ties, c, 10))
 
 
+def test_gftt_no_limit_semantics(pmv, orc, gpu_ctx_factory):
+    """cv::goodFeaturesToTrack(maxCorners <= 0) returns every corner that survives the min-distance rule; ShiTomasi's loop
+    (ShiTomasiFeatureExtractor.cpp:37-44) returns nothing for max <= 0."""
+    cfg = KITTI07
+    fr = _frames(pmv, cfg, 1, seed=1003)[0]
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=1)
+    ctx.frame_upload(0, fr)
+    cells = pmv.grid_cells(cfg["w"], cfg["h"])
+    for mx in (0, -3):
+        got = ctx.detect_gftt(0, cells, mx)
+        for c, g in zip(cells, got):
+            ref = orc.gftt_cell(fr, c, 65536)     # the oracle's "no limit": a bound no cell can reach
+            ref0 = orc.gftt_cell(fr, c, mx) if mx == 0 else ref
+            assert np.array_equal(ref, ref0)
+            assert len(g) > 80 and np.array_equal(g, ref)
+        assert all(len(xy) == 0 for xy, _ in ctx.detect_shitomasi(0, cells, mx))
+    # more corners than the documented capacity of the no-limit form is an error, not a silent truncation; the next call is clean
+    rng = np.random.default_rng(9)
+    noise = rng.integers(0, 256, (cfg["h"], cfg["w"]), dtype=np.uint8)
+    ctx.frame_upload(0, noise)
+    with pytest.raises(pmv.PmvError) as e:
+        ctx.detect_gftt(0, cells, 0, min_dist=0.5)
+    assert e.value.code == -6
+    got = ctx.detect_gftt(0, cells, 40)
+    for c, g in zip(cells, got):
+        assert np.array_equal(g, orc.gftt_cell(noise, c, 40))
+
+
+def test_detector_overflow_does_not_poison_later_calls(pmv, orc, gpu_ctx_factory):
+    """A candidate-list overflow (status bit set by the kernel) is reported for THAT call only."""
+    w, h = 300, 280
+    tile = np.array([[10, 120, 60], [100, 5, 90], [40, 110, 20]], np.uint8)   # period-3 texture: thousands of equal responses
+    img = np.tile(tile, (h // 3 + 1, w // 3 + 1))[:h, :w].copy()
+    ctx = gpu_ctx_factory(w, h, n_slots=1)
+    cells = pmv.grid_cells(w, h)
+    ctx.frame_upload(0, img)
+    with pytest.raises(pmv.PmvError) as e:
+        ctx.detect_shitomasi(0, cells, 40)
+    assert e.value.code == -6     # PMV_ERR_OVERFLOW: more than 8192 pixels above 0.4 * max in a cell
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ctx.frame_upload(0, noise)
+    for c, (gxy, gsc) in zip(cells, ctx.detect_shitomasi(0, cells, 40)):      # same context, next call: succeeds and is exact
+        rxy, rsc = orc.shitomasi_cell(noise, c, 40)
+        assert np.array_equal(gxy, rxy) and np.array_equal(gsc, rsc)
+    for c, g in zip(cells, ctx.detect_gftt(0, cells, 40)):
+        assert np.array_equal(g, orc.gftt_cell(noise, c, 40))
+
+
 def test_shitomasi_matches_oracle(pmv, orc, gpu_ctx_factory):
     cfg = KITTI07
     fr = _frames(pmv, cfg, 1, seed=1001)[0]
