@@ -128,6 +128,23 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
 int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4,
                                const uint8_t* mask_in, double* out_Q, uint8_t* out_mask, int* out_good);
 
+/* ---- call log (parity tooling) -------------------------------------------------------------------------------------------
+ * While recording is on, every pmv_pnp_ransac / pmv_ba_solve / pmv_triangulate_candidates call of this context (also those
+ * made from inside pmv_pipeline_run) appends one blob holding its inputs and outputs, so that a test can replay the calls
+ * of a whole run, one by one, through another implementation ("teacher forcing"). Little-endian, tightly packed:
+ *   PnP:  int32 {0, m, iterations, n_inliers}; f32 obj[3m], img[2m]; f64 K[9], rvec_in[3], tvec_in[3], reproj_err, confidence;
+ *         f64 rvec_out[3], tvec_out[3]; int32 inliers[n_inliers]
+ *   BA:   int32 {1, nc, np, n_obs, max_iterations}; f64 cams_in[6nc], pts_in[3np], obs[2n_obs], K[9], huber;
+ *         int32 cam_idx[n_obs], pt_idx[n_obs]; f64 cams_out[6nc], pts_out[3np], summary[5] (initial, final cost, iterations,
+ *         successful steps, termination)
+ *   DLT:  int32 {2, n}; f64 q1[2n], q2[2n], P1x4[48]; u8 mask_in[n]; f64 Q[16n]; u8 mask[4n]; int32 good[4]
+ * pmv_record_enable(ctx, 1) clears the log and starts, (ctx, 0) stops (the log stays readable). Not thread-safe against a
+ * running pipeline: read after the run. */
+int pmv_record_enable(pmv_ctx* ctx, int on);
+int pmv_record_count(pmv_ctx* ctx);
+long long pmv_record_size(pmv_ctx* ctx, int i);
+int pmv_record_get(pmv_ctx* ctx, int i, void* out, long long capacity);
+
 /* ---- per-kernel timing (HIP events on the launching stream; used by bench.py for the roofline object) -------------- */
 int pmv_prof_enable(pmv_ctx* ctx, int on);  /* on != 0: reset counters and start recording; 0: stop */
 int pmv_prof_select(pmv_ctx* ctx, unsigned mask); /* after pmv_prof_enable(1): record only classes whose bit (= id) is set */

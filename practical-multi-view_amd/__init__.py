@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frame_get_level", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates",
+    "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
     "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_prof_kernel_name", "pmv_prof_read",
     "pmv_pipeline_run", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
     "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_stats_count", "pmv_pipeline_get_stats",
@@ -92,6 +93,41 @@ class PipelineResult:
             self.free()
         except Exception:
             pass
+
+
+def parse_record(buf):
+    """one blob of the call log (layout: include/pmv_hip.h, "call log")"""
+    pos = [0]
+    raw = buf.tobytes()
+
+    def take(dtype, count):
+        nb = np.dtype(dtype).itemsize * count
+        a = np.frombuffer(raw[pos[0]:pos[0] + nb], dtype=dtype).copy()
+        pos[0] += nb
+        return a
+    kind = int(take(np.int32, 1)[0])
+    if kind == 0:
+        m, iters, nin = [int(v) for v in take(np.int32, 3)]
+        r = dict(kind="pnp", m=m, iterations=iters, obj=take(np.float32, 3 * m).reshape(m, 3), img=take(np.float32, 2 * m).reshape(m, 2),
+                 K=take(np.float64, 9), rvec_in=take(np.float64, 3), tvec_in=take(np.float64, 3))
+        opt = take(np.float64, 2)
+        r.update(reproj_err=float(opt[0]), confidence=float(opt[1]), rvec=take(np.float64, 3), tvec=take(np.float64, 3), inliers=take(np.int32, nin))
+    elif kind == 1:
+        nc, npnt, nobs, iters = [int(v) for v in take(np.int32, 4)]
+        r = dict(kind="ba", nc=nc, np=npnt, n_obs=nobs, max_iterations=iters, cams_in=take(np.float64, 6 * nc).reshape(nc, 6),
+                 pts_in=take(np.float64, 3 * npnt).reshape(npnt, 3), obs=take(np.float64, 2 * nobs).reshape(nobs, 2), K=take(np.float64, 9),
+                 huber=float(take(np.float64, 1)[0]), cam_idx=take(np.int32, nobs), pt_idx=take(np.int32, nobs))
+        r.update(cams=take(np.float64, 6 * nc).reshape(nc, 6), pts=take(np.float64, 3 * npnt).reshape(npnt, 3))
+        sm = take(np.float64, 5)
+        r.update(initial_cost=float(sm[0]), final_cost=float(sm[1]), iterations=int(sm[2]), successful_steps=int(sm[3]), termination=int(sm[4]))
+    elif kind == 2:
+        n = int(take(np.int32, 1)[0])
+        r = dict(kind="dlt", n=n, q1=take(np.float64, 2 * n).reshape(n, 2), q2=take(np.float64, 2 * n).reshape(n, 2), P1x4=take(np.float64, 48),
+                 mask_in=take(np.uint8, n), Q=take(np.float64, 16 * n).reshape(4, 4, n), mask=take(np.uint8, 4 * n).reshape(4, n), good=take(np.int32, 4))
+    else:
+        raise ValueError(f"unknown record kind {kind}")
+    assert pos[0] == len(buf), "record length does not match its header"
+    return r
 
 
 _lib = None
@@ -318,6 +354,23 @@ class Context:
         self._ck(self.lib.pmv_triangulate_candidates(self.h, _p(q1, _f64p), _p(q2, _f64p), n, _p(P, _f64p), _p(mi, _u8p),
                                                      _p(Q, _f64p), _p(mask, _u8p), _p(good, _i32p)))
         return Q, mask, good
+
+    # ---- call log (teacher-forced replay) ----
+    def record_enable(self, on=True):
+        self._ck(self.lib.pmv_record_enable(self.h, 1 if on else 0))
+
+    def records(self):
+        """the logged back-end calls as dicts (kind 'pnp' | 'ba' | 'dlt') with numpy views of inputs and outputs"""
+        self.lib.pmv_record_size.restype = C.c_longlong
+        self.lib.pmv_record_size.argtypes = [C.c_void_p, C.c_int]
+        self.lib.pmv_record_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+        out = []
+        for i in range(self.lib.pmv_record_count(self.h)):
+            nb = self.lib.pmv_record_size(self.h, i)
+            buf = np.zeros(nb, np.uint8)
+            self._ck(self.lib.pmv_record_get(self.h, i, buf.ctypes.data_as(C.c_void_p), nb))
+            out.append(parse_record(buf))
+        return out
 
     # ---- per-kernel HIP-event timing ----
     def prof_enable(self, on=True):

@@ -197,9 +197,37 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     const int* h_info = (const int*)(ho + 48);
     const int* h_inl = (const int*)(ho + 64);
     const int n = h_info[0];
+    if (ctx->log.on) {   // [kind 0, m, iterations, n_inliers | obj 3m f32 | img 2m f32 | K 9, rvec_in 3, tvec_in 3, reproj_err, confidence f64 | rvec_out 3, tvec_out 3 f64 | inliers]
+        ctx->log.blobs.emplace_back();
+        std::vector<char>& bl = ctx->log.blobs.back();
+        const int hdr[4] = {0, m, iterations, n};
+        const double opt[2] = {(double)reproj_err, confidence};
+        pmv_call_log::put(bl, hdr, 16); pmv_call_log::put(bl, obj_xyz, (size_t)m * 12); pmv_call_log::put(bl, img_xy, (size_t)m * 8);
+        pmv_call_log::put(bl, K, 72); pmv_call_log::put(bl, rvec, 24); pmv_call_log::put(bl, tvec, 24); pmv_call_log::put(bl, opt, 16);
+        pmv_call_log::put(bl, h_rt, 48); pmv_call_log::put(bl, h_inl, (size_t)(n > 0 ? n : 0) * 4);
+    }
     for (int i = 0; i < 3; i++) { rvec[i] = h_rt[i]; tvec[i] = h_rt[3 + i]; }
     *out_n_inliers = n;
     if (n > 0) memcpy(out_inliers, h_inl, (size_t)n * 4);
+    return PMV_OK;
+}
+
+// ---- call log (teacher-forced replay of a pipeline run's back-end calls through another implementation) ----------------
+int pmv_record_enable(pmv_ctx* ctx, int on) {
+    REQ(ctx, PMV_ERR_INVALID, "null ctx");
+    if (on) ctx->log.blobs.clear();
+    ctx->log.on = on != 0;
+    return PMV_OK;
+}
+int pmv_record_count(pmv_ctx* ctx) { return ctx ? (int)ctx->log.blobs.size() : PMV_ERR_INVALID; }
+long long pmv_record_size(pmv_ctx* ctx, int i) {
+    if (!ctx || i < 0 || i >= (int)ctx->log.blobs.size()) return PMV_ERR_INVALID;
+    return (long long)ctx->log.blobs[i].size();
+}
+int pmv_record_get(pmv_ctx* ctx, int i, void* out, long long capacity) {
+    REQ(ctx && out && i >= 0 && i < (int)ctx->log.blobs.size(), PMV_ERR_INVALID, "pmv_record_get: bad argument");
+    REQ(capacity >= (long long)ctx->log.blobs[i].size(), PMV_ERR_CAPACITY, "pmv_record_get: buffer too small");
+    memcpy(out, ctx->log.blobs[i].data(), ctx->log.blobs[i].size());
     return PMV_OK;
 }
 
@@ -386,6 +414,15 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
             fprintf(stderr, "\n");
         }
     }
+    if (ctx->log.on) {   // [kind 1, nc, np, n_obs, max_iterations | cams_in 6nc, pts_in 3np, obs 2n_obs, K 9, huber f64 | cam_idx, pt_idx i32 | cams_out, pts_out, summary 5 f64]
+        ctx->log.blobs.emplace_back();
+        std::vector<char>& bl = ctx->log.blobs.back();
+        const int hdr[5] = {1, nc, np, n_obs, max_iterations};
+        pmv_call_log::put(bl, hdr, 20); pmv_call_log::put(bl, cams, (size_t)nc * 48); pmv_call_log::put(bl, pts, (size_t)np * 24);
+        pmv_call_log::put(bl, obs_xy, (size_t)n_obs * 16); pmv_call_log::put(bl, K, 72); pmv_call_log::put(bl, &huber_delta, 8);
+        pmv_call_log::put(bl, cam_idx, (size_t)n_obs * 4); pmv_call_log::put(bl, pt_idx, (size_t)n_obs * 4);
+        pmv_call_log::put(bl, h_out + 8, ((size_t)nc * 6 + (size_t)np * 3) * 8); pmv_call_log::put(bl, h_out, 40);
+    }
     memcpy(cams, h_out + 8, (size_t)nc * 48);
     memcpy(pts, h_out + 8 + (size_t)nc * 6, (size_t)np * 24);
     if (summary) {
@@ -428,6 +465,14 @@ int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2,
         int g = 0;
         for (int i = 0; i < n; i++) g += out_mask[(size_t)c * n + i];
         out_good[c] = g;
+    }
+    if (ctx->log.on) {   // [kind 2, n | q1 2n, q2 2n, P 48 f64 | mask_in n u8 | Q 16n f64 | mask 4n u8 | good 4 i32]
+        ctx->log.blobs.emplace_back();
+        std::vector<char>& bl = ctx->log.blobs.back();
+        const int hdr[2] = {2, n};
+        pmv_call_log::put(bl, hdr, 8); pmv_call_log::put(bl, q1, (size_t)n * 16); pmv_call_log::put(bl, q2, (size_t)n * 16); pmv_call_log::put(bl, P1x4, 384);
+        pmv_call_log::put(bl, mask_in, (size_t)n); pmv_call_log::put(bl, out_Q, (size_t)n * 128); pmv_call_log::put(bl, out_mask, (size_t)n * 4);
+        pmv_call_log::put(bl, out_good, 16);
     }
     return PMV_OK;
 }

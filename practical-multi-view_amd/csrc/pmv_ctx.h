@@ -11,6 +11,15 @@ constexpr int MAX_PER_CELL = 4096;    // also the capacity of an "unlimited" (ma
 struct BackendBuffers;              // PnP / BA device workspaces (backend.hip)
 }
 
+// In-memory log of the back-end plugin calls (pmv_record_*): every pmv_pnp_ransac / pmv_ba_solve / pmv_triangulate_candidates
+// call made while recording is on leaves one self-describing blob (layout: include/pmv_hip.h) with its inputs AND outputs, so a
+// test can replay exactly the calls a pipeline run made through another implementation. Back-end thread only.
+struct pmv_call_log {
+    bool on = false;
+    std::vector<std::vector<char>> blobs;
+    static void put(std::vector<char>& b, const void* p, size_t n) { const char* c = (const char*)p; b.insert(b.end(), c, c + n); }
+};
+
 struct pmv_ctx {
     int device = 0;
     int max_w = 0, max_h = 0, n_slots = 0, max_tracks = 0, max_ba_cams = 0, max_ba_points = 0, max_ba_obs = 0;
@@ -36,6 +45,7 @@ struct pmv_ctx {
     double* h_det_score = nullptr;
     pmv::BackendBuffers* be = nullptr;
     pmv::Profiler prof;
+    pmv_call_log log;
     char err[512] = "";
 };
 

@@ -205,6 +205,19 @@ def pnp_ransac(obj, img, K, rvec, tvec, iterations=100, reproj_err=8.0, confiden
     return rv, tv, inl[:max(n, 0)].copy(), hu.value
 
 
+def pnp_hypotheses(obj, img, K, iterations=100, reproj_err=8.0):
+    """models (iterations, 6: rvec, tvec) and inlier counts of every RANSAC hypothesis (no adaptive cut-off)"""
+    lib = load().lib
+    o = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    i2 = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+    models = np.zeros((iterations, 6), np.float64)
+    counts = np.zeros(iterations, np.int32)
+    lib.orc_pnp_hypotheses(_p(o, _f32p), _p(i2, _f32p), o.shape[0], _p(Kd, _f64p), iterations, C.c_float(reproj_err),
+                           _p(models, _f64p), _p(counts, _i32p))
+    return models, counts
+
+
 def rodrigues_v2m(r):
     R = np.zeros(9)
     load().lib.orc_rodrigues_v2m(_p(np.ascontiguousarray(r, np.float64), _f64p), _p(R, _f64p))

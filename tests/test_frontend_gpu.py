@@ -117,14 +117,13 @@ def test_detector_overflow_does_not_poison_later_calls(pmv, orc, gpu_ctx_factory
     with pytest.raises(pmv.PmvError) as e:
         ctx.detect_shitomasi(0, cells, 40)
     assert e.value.code == -6     # PMV_ERR_OVERFLOW: more than 8192 pixels above 0.4 * max in a cell
-    rng = np.random.default_rng(5)
-    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
-    ctx.frame_upload(0, noise)
+    scene = _frames(pmv, KITTI07, 1, seed=1001)[0][:h, :w].copy()
+    ctx.frame_upload(0, scene)
     for c, (gxy, gsc) in zip(cells, ctx.detect_shitomasi(0, cells, 40)):      # same context, next call: succeeds and is exact
-        rxy, rsc = orc.shitomasi_cell(noise, c, 40)
+        rxy, rsc = orc.shitomasi_cell(scene, c, 40)
         assert np.array_equal(gxy, rxy) and np.array_equal(gsc, rsc)
     for c, g in zip(cells, ctx.detect_gftt(0, cells, 40)):
-        assert np.array_equal(g, orc.gftt_cell(noise, c, 40))
+        assert np.array_equal(g, orc.gftt_cell(scene, c, 40))
 
 
 def test_shitomasi_matches_oracle(pmv, orc, gpu_ctx_factory):

@@ -33,7 +33,12 @@ def _run_both(pmv, gpu_ctx_factory, cfg, n, seed, threaded=0, **kw):
     return g, o, poses
 
 
-MIN_TIGHT = 3   # frames whose final pose is written by the first BA only (bundle 10: frames 0-2; smaller bundles: more)
+# Frames that must agree to 1e-6 before any discrete flip may have happened. Measured first flips (round 2, MI355X, printed by
+# every test): config1 37/49, metric prefix 27/59, 800 tracks / bundle 10: 32/35, ShiTomasi 22/22 (none), 1080p / 2000 tracks /
+# bundle 20: 6/37; each test demands ~70 % of its measured value, so a kernel change that moves a summation order has room while a
+# real defect (poses wrong from the first PnP/BA on) cannot pass. Per-call parity on the pipeline's real inputs, which does not
+# depend on where the first flip falls, is tests/test_replay_gpu.py.
+MIN_TIGHT = 3   # floor for any configuration: frames whose final pose is written by the first BA only
 
 
 def _compare(g, o, pose_tol, min_tight=MIN_TIGHT):
@@ -58,7 +63,7 @@ def _compare(g, o, pose_tol, min_tight=MIN_TIGHT):
 def test_config1_plumbing_case(pmv, gpu_ctx_factory):
     """BASELINE configs[0]: 50 frames, 200 tracks (tol 75), bundle_size 3."""
     g, o, gt = _run_both(pmv, gpu_ctx_factory, K07, 50, 1007, min_tracked=200, tol=75, bundle_size=3)
-    _compare(g, o, 1e-6)
+    _compare(g, o, 1e-6, min_tight=26)
     # the trajectory is a sane odometry of the synthetic drive (forward = -z in the pipeline's frame, quirk Q14)
     z = g.poses[:, 11]
     gz = -(gt[: len(z), 11] - gt[0, 11])
@@ -68,7 +73,7 @@ def test_config1_plumbing_case(pmv, gpu_ctx_factory):
 def test_metric_config_prefix(pmv, gpu_ctx_factory):
     """BASELINE configs[1] (metric config: 400 tracks, tol 150, bundle 5), first 60 frames."""
     g, o, _ = _run_both(pmv, gpu_ctx_factory, K07, 60, 1007)
-    _compare(g, o, 1e-6)
+    _compare(g, o, 1e-6, min_tight=19)
 
 
 def test_threaded_schedule_gives_identical_results(pmv, gpu_ctx_factory):
@@ -87,12 +92,12 @@ def test_threaded_schedule_gives_identical_results(pmv, gpu_ctx_factory):
 
 def test_config3_like_800_tracks_bundle10(pmv, gpu_ctx_factory):
     g, o, _ = _run_both(pmv, gpu_ctx_factory, K00, 36, 1000, min_tracked=800, tol=300, bundle_size=10)
-    _compare(g, o, 1e-6)
+    _compare(g, o, 1e-6, min_tight=22)
 
 
 def test_shitomasi_extractor_pipeline(pmv, gpu_ctx_factory):
     g, o, _ = _run_both(pmv, gpu_ctx_factory, K07, 24, 1003, extractor=1)
-    _compare(g, o, 1e-6)
+    _compare(g, o, 1e-6, min_tight=15)
 
 
 def test_config4_like_1080p_2000_tracks_bundle20(pmv, gpu_ctx_factory):
@@ -100,8 +105,11 @@ def test_config4_like_1080p_2000_tracks_bundle20(pmv, gpu_ctx_factory):
     up to 20 cameras = a 120x120 reduced system): short run, same bars as the other configs."""
     cfg = dict(w=1920, h=1080, fx=1000.0, fy=1000.0, cx=960.0, cy=540.0)
     g, o, _ = _run_both(pmv, gpu_ctx_factory, cfg, 40, 1010, min_tracked=2000, tol=750, bundle_size=20)
-    _compare(g, o, 1e-6)
+    _compare(g, o, 1e-6, min_tight=4)
     assert g.stats["ba_calls"] >= 2 and g.stats["lk_points"] > 20 * 1500
+
+
+FULL_RUN_TIGHT = 45   # measured: 69 of 1100 (see MIN_TIGHT)
 
 
 def test_metric_config_full_sequence(pmv, gpu_ctx_factory):
@@ -123,6 +131,10 @@ def test_metric_config_full_sequence(pmv, gpu_ctx_factory):
     travelled = np.linalg.norm(o.poses[:, 9:12], axis=1)
     dt = np.linalg.norm(g.poses[:, 9:12] - o.poses[:, 9:12], axis=1)
     assert (dt <= 0.02 * travelled + 0.05).all(), f"trajectories drift apart: {dt.max()}"
+    bad = np.nonzero(np.abs(g.poses - o.poses).max(axis=1) > 1e-6)[0]
+    first_flip = int(bad[0]) if len(bad) else len(g.poses)
+    print(f"full metric run: poses agree to 1e-6 for the first {first_flip} of {len(g.poses)} frames")
+    assert first_flip >= FULL_RUN_TIGHT
 
 
 def test_result_lifetime_variants(pmv, gpu_ctx_factory):
@@ -138,3 +150,54 @@ def test_result_lifetime_variants(pmv, gpu_ctx_factory):
     assert np.array_equal(a.poses, b.poses) and np.array_equal(a.poses, c.poses)
     b.free(); b.free()          # idempotent
     ctx.pipeline_drain()
+
+
+def test_config5_eight_sequences_sharded_one_per_rank(pmv, gpu_ctx_factory):
+    """BASELINE configs[4]: eight sequences with the KITTI 00-07 length profile (scaled 1/25: 182, 44, 186, 32, 11, 110, 44, 44
+    frames), 400 tracks each, bundle 5, dealt to ranks by sharding.assign_sequences. One GPU stands in for the node: every rank
+    is a host thread with its own context (its own streams and HBM slots), all eight in flight at once. Every sequence must be
+    bitwise equal to its own independent single run (no cross-talk between contexts, any world size) and agree with the oracle:
+    features bit-exact, poses to the end-to-end bar."""
+    import importlib
+    import threading
+    sh = importlib.import_module("practical-multi-view_amd.sharding")
+    cfg = K00
+    lengths = [max(11, round(L / 25)) for L in sh.KITTI_LENGTHS]
+    assert lengths == [182, 44, 186, 32, 11, 110, 44, 44]
+    K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+    seqs = [pmv.synth_sequence(1000 + sid, 0, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16) for sid, n in enumerate(lengths)]
+
+    def run_world(world):
+        ranks = sh.assign_sequences(lengths, world)
+        out = [None] * len(lengths)
+        errs = []
+
+        def rank_main(r):
+            try:
+                ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=max(lengths[i] for i in ranks[r]), max_tracks=4096)
+                for sid in ranks[r]:                         # a rank processes its sequences in order, like bench.py --config 5
+                    frames, gt = seqs[sid]
+                    ctx.frames_stage(0, frames)
+                    out[sid] = ctx.pipeline_run(lengths[sid], cfg["w"], cfg["h"], K, gt, threaded=1, n_threads=2)
+            except Exception as e:   # noqa: BLE001
+                errs.append((r, e))
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        return out
+
+    single = run_world(1)      # one rank runs the eight sequences one after the other: the independent single runs
+    for world in (8, 2):
+        got = run_world(world)
+        for sid in range(len(lengths)):
+            assert np.array_equal(got[sid].poses, single[sid].poses), f"world {world}: sequence {sid} differs from its single run"
+            for a, b in zip(got[sid].features, single[sid].features):
+                assert np.array_equal(a, b)
+    for sid in range(len(lengths)):
+        frames, gt = seqs[sid]
+        o = ob.run_pipeline(frames, K, gt, threaded=1, n_threads=8)
+        print(f"sequence {sid} ({lengths[sid]} frames):", end=" ")
+        _compare(single[sid], o, 1e-6, min_tight=min(MIN_TIGHT, len(o.poses)))
