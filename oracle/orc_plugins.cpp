@@ -140,14 +140,94 @@ int orc_host_corr_order(const int* cols, const int* rows, int n, int* out_key, i
     for (auto& p : corr) { out_key[k] = si[p.first.lock().get()]; out_val[k] = di[p.second.lock().get()]; k++; }
     return k;
 }
-// OdometryPipeline.cpp:407 trigger and CeresBundleAdjustment.cpp:7-8,20-23 window for estimatePose(src_frame, src_frame+1)
-int orc_host_ba_schedule(int bundle_size, int src_frame, int* win_first, int* win_count) {
-    const int trig = bundle_size && src_frame && src_frame % (bundle_size / 3 * 2) == 0;
-    const int fn = src_frame + 1 + 1, n = std::min(bundle_size, fn);
-    int cnt = 0, first = -1;
-    for (int i = fn - n; i < fn; i++) { if (i == 0) continue; if (first < 0) first = i; cnt++; }
-    *win_first = first; *win_count = cnt;
-    return trig;
+// OdometryPipeline.cpp:407 trigger and CeresBundleAdjustment.cpp:7-8,20-23 window, PROBED on the real code: a pipeline of
+// n_frames frames (every frame observes one common landmark, so every window camera enters the problem; t[i] = (i, 0, 0) tags
+// the frames) is driven through OdometryPipeline::estimatePose with a pose plugin that does nothing and an optimizer hook that
+// records what BundleAdjustmentBase::apply hands to the solver. out_trig[j] = 1 if estimatePose(frames[j], frames[j+1]) ran BA;
+// out_first[j] / out_count[j] = first window frame / number of cameras of that call.
+namespace {
+struct NullPnP : vo::BasePnPSolver { void solvePnP(vo::Frame&, vo::Frame&, vo::Mat3&, vo::Vec3&) override {} };
+struct RecordingBA : vo::BundleAdjustmentBase {
+    int calls = 0, last_nc = 0, last_first = -1;
+    void ba_solve(double* cams, int nc, double*, int, const double*, const int*, const int*, int, const double*, double, int) override {
+        calls++; last_nc = nc;
+        last_first = (int)std::lround(-cams[3]);   // cams = [aa(R^T), -t], t[i] = (i, 0, 0)
+    }
+};
+}
+void orc_host_ba_schedule(int bundle_size, int n_frames, int* out_trig, int* out_first, int* out_count) {
+    vo::OdometryPipeline pl;
+    pl.cfg.bundle_size = bundle_size;
+    pl.cfg.tracked_features_tol = 0;   // count3DPoints() >= 0: always the PnP branch
+    NullPnP pnp; RecordingBA ba; ba.tracker = &pl;
+    pl.pnpsolver = &pnp; pl.ba = &ba;
+    auto lm = std::make_shared<vo::Feature3D>(1.0, 2.0, -9.0);
+    lm->id = 0;
+    pl.feats3d.push_back(lm);
+    for (int i = 0; i < n_frames; i++) {
+        auto fr = std::make_shared<vo::Frame>();
+        fr->frame = i;
+        fr->map[std::make_shared<vo::Feature>(10 + i, 20)] = lm;
+        pl.frames.push_back(fr);
+    }
+    pl.scale = 1.0;
+    pl.R.push_back(vo::Mat3::eye()); pl.t.push_back(vo::Vec3{{0, 0, 0}});
+    pl.R_s.push_back(vo::Mat3::eye()); pl.t_s.push_back(vo::Vec3{{0, 0, 0}});
+    for (int j = 0; j + 1 < n_frames; j++) {
+        const int before = ba.calls;
+        pl.estimatePose(*pl.frames[j], *pl.frames[j + 1]);
+        // motionHeuristics appended pose j+1; retag it so the next window can be read off the camera block
+        pl.R[j + 1] = vo::Mat3::eye(); pl.t[j + 1] = vo::Vec3{{(double)(j + 1), 0, 0}};
+        out_trig[j] = ba.calls > before;
+        out_first[j] = out_trig[j] ? ba.last_first : -1;
+        out_count[j] = out_trig[j] ? ba.last_nc : 0;
+    }
+}
+// OdometryPipeline::motionHeuristics (:171-208) on a pipeline whose pose history is given: R/t/R_s/t_s hold n entries (9 / 3
+// doubles each); (_R, _t) is the relative motion handed in; j the source frame. Outputs: the absolute pose appended to R/t, the
+// relative pose appended to R_s/t_s, and whether the fallback branch was taken.
+int orc_host_motion_heuristics(int n, const double* R, const double* t, const double* Rs, const double* ts, double scale, int j,
+                               const double* R_in, const double* t_in, double* R_abs, double* t_abs, double* R_rel, double* t_rel) {
+    vo::OdometryPipeline pl;
+    pl.scale = scale;
+    for (int i = 0; i < n; i++) {
+        vo::Mat3 a, b; memcpy(a.m, R + 9 * i, 72); memcpy(b.m, Rs + 9 * i, 72);
+        pl.R.push_back(a); pl.R_s.push_back(b);
+        pl.t.push_back(vo::Vec3{{t[3 * i], t[3 * i + 1], t[3 * i + 2]}});
+        pl.t_s.push_back(vo::Vec3{{ts[3 * i], ts[3 * i + 1], ts[3 * i + 2]}});
+    }
+    vo::Mat3 _R; memcpy(_R.m, R_in, 72);
+    vo::Vec3 _t{{t_in[0], t_in[1], t_in[2]}};
+    pl.motionHeuristics(_R, _t, j);
+    memcpy(R_abs, pl.R.back().m, 72); memcpy(t_abs, pl.t.back().v, 24);
+    memcpy(R_rel, pl.R_s.back().m, 72); memcpy(t_rel, pl.t_s.back().v, 24);
+    return (int)pl.stats.heuristic_motion;
+}
+// ---- two-view geometry probes (vo_fivepoint.cpp; the host triangulator is shared by product and oracle pipelines, so its
+// known-answer tests go straight at the functions, not through a pipeline) ----
+int orc_host_five_point(const double* q1, const double* q2, double* E_out) { return vo::five_point_essentials(q1, q2, E_out); }
+void orc_host_five_point_samples(int n, int count, int* out5) { vo::five_point_sample_stream(n, count, out5); }
+int orc_host_update_num_iters(double p, double ep, int mp, int mx) { return vo::five_point_update_num_iters(p, ep, mp, mx); }
+int orc_host_find_essential(const double* p1, const double* p2, int n, const double* K, double prob, double threshold, double* E,
+                            unsigned char* mask_out, int* samples_drawn, int workers) {
+    std::vector<uint8_t> mask;
+    int drawn = 0;
+    std::shared_ptr<vo::SpinPool> pool;
+    if (workers > 1) pool = vo::make_spin_pool(workers - 1);
+    const bool ok = vo::find_essential_mat(p1, p2, n, K, prob, threshold, E, mask, &drawn, pool.get(), workers);
+    memcpy(mask_out, mask.data(), (size_t)n);
+    if (samples_drawn) *samples_drawn = drawn;
+    return ok ? 1 : 0;
+}
+int orc_host_recover_pose(const double* E, const double* p1, const double* p2, int n, const double* K, double* R, double* t,
+                          unsigned char* mask_io, double* tri4) {
+    vo::FivePointTri tri;   // host DLT hook
+    std::vector<uint8_t> mask(mask_io, mask_io + n);
+    std::vector<double> q;
+    const int good = vo::recover_pose(&tri, E, p1, p2, n, K, R, t, mask, q);
+    memcpy(mask_io, mask.data(), (size_t)n);
+    memcpy(tri4, q.data(), (size_t)4 * n * sizeof(double));
+    return good;
 }
 // the per-point part of cv::recoverPose (OpenCVFivePointTri.cpp:27): the checker for pmv_triangulate_candidates
 void orc_triangulate_candidates(const double* q1, const double* q2, int n, const double* P1x4, const unsigned char* mask_in, double* out_Q,

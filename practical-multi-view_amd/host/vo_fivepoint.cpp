@@ -263,6 +263,20 @@ void sampson_errors(const double* E, const double* q1, const double* q2, int n, 
     }
 }
 
+// RANSACPointSetRegistrator::getSubset: modelPoints distinct indices in [0, n), rejection sampling on the MWC stream
+void draw_subset(RNG& rng, int n, int modelPoints, int* idx) {
+    for (int i = 0; i < modelPoints;) {
+        int idx_i;
+        for (;;) {
+            idx_i = idx[i] = rng.uniform(0, n);
+            int j = 0;
+            for (; j < i; j++) if (idx_i == idx[j]) break;
+            if (j == i) break;
+        }
+        i++;
+    }
+}
+
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     p = std::max(p, 0.); p = std::min(p, 1.);
     ep = std::max(ep, 0.); ep = std::min(ep, 1.);
@@ -275,6 +289,14 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) 
 }
 
 }  // namespace
+
+int five_point_essentials(const double* q1, const double* q2, double* E_out) { return five_point_kernel(q1, q2, E_out); }
+// the first `count` 5-subsets findEssentialMat's RANSAC draws for n correspondences (cv::RNG seeded (uint64)-1 per call)
+void five_point_sample_stream(int n, int count, int* out5) {
+    RNG rng((uint64_t)-1);
+    for (int k = 0; k < count; k++) draw_subset(rng, n, 5, out5 + 5 * k);
+}
+int five_point_update_num_iters(double p, double ep, int model_points, int max_iters) { return ransac_update_num_iters(p, ep, model_points, max_iters); }
 
 // Helper threads for the five-point RANSAC: the hypotheses of a batch are independent, so they are evaluated side by side and
 // the sequential bookkeeping (best-so-far, adaptive iteration count) is replayed in sample order afterwards — the outcome is
@@ -333,8 +355,10 @@ private:
 };
 
 // cv::findEssentialMat(points1, points2, K, RANSAC, prob, threshold, mask): returns false when no model was found
+std::shared_ptr<SpinPool> make_spin_pool(int workers) { return std::make_shared<SpinPool>(workers); }
+
 bool find_essential_mat(const double* p1, const double* p2, int n, const double* K, double prob, double threshold,
-                        double* E, std::vector<uint8_t>& mask, int* samples_drawn = nullptr, SpinPool* pool = nullptr, int pool_width = 1) {
+                        double* E, std::vector<uint8_t>& mask, int* samples_drawn, SpinPool* pool, int pool_width) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     std::vector<double> q1(2 * n), q2(2 * n);
     for (int i = 0; i < n; i++) {
@@ -371,18 +395,7 @@ bool find_essential_mat(const double* p1, const double* p2, int n, const double*
         mask.assign(n, 1);
         return true;
     }
-    auto draw = [&](int* idx) {   // RANSACPointSetRegistrator::getSubset: 5 distinct indices
-        for (int i = 0; i < modelPoints;) {
-            int idx_i;
-            for (;;) {
-                idx_i = idx[i] = rng.uniform(0, n);
-                int j = 0;
-                for (; j < i; j++) if (idx_i == idx[j]) break;
-                if (j == i) break;
-            }
-            i++;
-        }
-    };
+    auto draw = [&](int* idx) { draw_subset(rng, n, modelPoints, idx); };
     if (!pool || pool_width <= 1) {
         for (int iter = 0; iter < niters; iter++) {
             if (samples_drawn) ++*samples_drawn;

@@ -162,6 +162,20 @@ public:
     std::function<void(int)> on_frame_added;            // optional hook (e.g. bench progress)
 };
 
+// ---- two-view geometry of the triangulator (vo_fivepoint.cpp), exposed for known-answer tests -------------------------------
+// EMEstimatorCallback::runKernel: five NORMALISED correspondences -> up to 10 essential matrices (row-major, unit Frobenius norm)
+int five_point_essentials(const double* q1, const double* q2, double* E_out);
+void five_point_sample_stream(int n, int count, int* out5);   // the RANSAC's index stream (getSubset on cv::RNG((uint64)-1))
+int five_point_update_num_iters(double p, double ep, int model_points, int max_iters);   // cv::RANSACUpdateNumIters
+// cv::findEssentialMat(points1, points2, K, RANSAC, prob, threshold, mask) on pixel coordinates; samples_drawn counts RANSAC
+// iterations; pool/pool_width: helper threads (results do not depend on them)
+bool find_essential_mat(const double* p1, const double* p2, int n, const double* K, double prob, double threshold, double* E,
+                        std::vector<uint8_t>& mask, int* samples_drawn, SpinPool* pool, int pool_width);
+// cv::recoverPose(E, points1, points2, K, R, t, HUGE_VAL, mask (in/out), triangulatedPoints): returns the number of good points
+int recover_pose(FivePointTri* self, const double* E, const double* p1, const double* p2, int n, const double* K, double* R_out,
+                 double* t_out, std::vector<uint8_t>& mask, std::vector<double>& tri4);
+std::shared_ptr<SpinPool> make_spin_pool(int workers);
+
 // cv::Rodrigues both ways (host copy for the adapters)
 void rodrigues_v2m(const double r[3], double R[9]);
 void rodrigues_m2v(const double R[9], double r[3]);

@@ -131,20 +131,27 @@ def test_ba_noiseless_converges_and_zero_iterations_is_identity():
 
 
 def test_ba_trigger_schedule_and_window(orc):
-    """KA9: OdometryPipeline.cpp:407 (integer arithmetic!) and CeresBundleAdjustment.cpp:7-8,20-23."""
-    wf, wc = C.c_int(), C.c_int()
-
-    def q(b, j):
-        trig = orc.lib.orc_host_ba_schedule(b, j, C.byref(wf), C.byref(wc))
-        return trig, wf.value, wc.value
-    for b, period in ((3, 2), (5, 2), (10, 6), (20, 12)):
-        trig = [j for j in range(0, 40) if q(b, j)[0]]
-        assert trig == [j for j in range(1, 40) if j % period == 0]
-    assert q(5, 2) == (1, 1, 3)        # next = frame 3: window frames {0..3} minus frame 0, n = min(5, 4)
-    assert q(5, 10) == (1, 7, 5)       # frames 7..11
-    assert q(3, 2) == (1, 1, 3)
-    assert q(10, 6) == (1, 1, 7)       # fn = 8 < bundle: frames 1..7
-    assert q(0, 4)[0] == 0
+    """KA9: OdometryPipeline.cpp:407 (integer arithmetic!) and CeresBundleAdjustment.cpp:7-8,20-23, probed on the REAL
+    estimatePose / BundleAdjustmentBase::apply code (a pipeline with a do-nothing pose plugin and a recording optimizer hook),
+    against the schedule written down here from the reference source."""
+    N = 42
+    for b in (3, 5, 10, 20, 0):
+        trig = np.zeros(N, np.int32); first = np.zeros(N, np.int32); count = np.zeros(N, np.int32)
+        ip = C.POINTER(C.c_int)
+        orc.lib.orc_host_ba_schedule(b, N, trig.ctypes.data_as(ip), first.ctypes.data_as(ip), count.ctypes.data_as(ip))
+        for j in range(N - 1):
+            want_trig = bool(b) and j != 0 and j % (b // 3 * 2) == 0                  # :407, src.frame = j
+            assert bool(trig[j]) == want_trig, (b, j)
+            if want_trig:
+                fn = (j + 1) + 1                                                       # apply(next): fn = next.frame + 1
+                n = min(b, fn)
+                window = [i for i in range(fn - n, fn) if i != 0]                     # :20-23 skips frame 0
+                assert (first[j], count[j]) == (window[0], len(window)), (b, j)
+    # spot values
+    trig = np.zeros(12, np.int32); first = np.zeros(12, np.int32); count = np.zeros(12, np.int32)
+    orc.lib.orc_host_ba_schedule(5, 12, trig.ctypes.data_as(ip), first.ctypes.data_as(ip), count.ctypes.data_as(ip))
+    assert list(trig[:11]) == [0, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1]
+    assert (first[2], count[2]) == (1, 3) and (first[10], count[10]) == (7, 5)
 
 
 def test_feature3d_float32_round_trip_quirk_q7(orc):

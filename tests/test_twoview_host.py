@@ -1,0 +1,279 @@
+"""Known-answer tests of the host code that product and oracle pipelines SHARE (practical-multi-view_amd/host/vo_fivepoint.cpp,
+vo_pipeline.cpp): an end-to-end "GPU vs oracle" comparison runs the same object code on both sides for these rows, so they are
+pinned here against answers that do not come from that code — closed-form geometry, numpy twins written from the reference's
+source (OdometryPipeline.cpp:171-208, OpenCVFivePointTri.cpp:24-27) and an independent re-implementation of cv::RNG /
+RANSACPointSetRegistrator::getSubset / RANSACUpdateNumIters. No GPU needed."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int)
+_u8p = C.POINTER(C.c_uint8)
+K = np.array([718.856, 0, 607.1928, 0, 718.856, 185.2157, 0, 0, 1.0])
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _rot(rv):
+    th = np.linalg.norm(rv)
+    if th == 0:
+        return np.eye(3)
+    k = rv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def _skew(t):
+    return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+
+
+def _scene(seed, n, noise_px=0.0, outlier_frac=0.0, integer=False):
+    """two views of a point cloud: camera 0 = [I|0], camera 1 = [R|t], |t| = 1; pixel coordinates p1, p2 (n, 2)"""
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-3, 2, n), rng.uniform(5, 40, n)], 1)
+    R = _rot(rng.normal(0, 0.03, 3))
+    t = np.array([0.08, -0.03, -1.0]) + rng.normal(0, 0.02, 3)
+    t /= np.linalg.norm(t)
+    Xc = X @ R.T + t
+
+    def proj(P):
+        return np.stack([P[:, 0] / P[:, 2] * K[0] + K[2], P[:, 1] / P[:, 2] * K[4] + K[5]], 1)
+    p1, p2 = proj(X), proj(Xc)
+    if noise_px:
+        p1 = p1 + rng.normal(0, noise_px, p1.shape)
+        p2 = p2 + rng.normal(0, noise_px, p2.shape)
+    out = rng.random(n) < outlier_frac
+    p2[out] += rng.uniform(15, 60, (int(out.sum()), 2)) * rng.choice([-1, 1], (int(out.sum()), 2))
+    if integer:
+        p1, p2 = np.floor(p1), np.floor(p2)
+    return dict(p1=np.ascontiguousarray(p1), p2=np.ascontiguousarray(p2), R=R, t=t, X=X, outliers=out)
+
+
+def _norm(p):
+    return np.ascontiguousarray(np.stack([(p[:, 0] - K[2]) / K[0], (p[:, 1] - K[5]) / K[4]], 1))
+
+
+def _same_up_to_sign(E, Etrue):
+    E = E / np.linalg.norm(E)
+    Etrue = Etrue / np.linalg.norm(Etrue)
+    return min(np.abs(E - Etrue).max(), np.abs(E + Etrue).max())
+
+
+def _find_essential(orc, p1, p2, prob=0.99, thr=1.0, workers=1):
+    n = len(p1)
+    E = np.zeros(9)
+    mask = np.zeros(n, np.uint8)
+    drawn = C.c_int()
+    ok = orc.lib.orc_host_find_essential(_p(p1, _f64p), _p(p2, _f64p), n, _p(K, _f64p), C.c_double(prob), C.c_double(thr), _p(E, _f64p),
+                                         _p(mask, _u8p), C.byref(drawn), workers)
+    return bool(ok), E.reshape(3, 3), mask, drawn.value
+
+
+# ---- independent twins of the OpenCV pieces the RANSAC loop is made of ------------------------------------
+class CvRNG:
+    def __init__(self, seed=2 ** 64 - 1):
+        self.state = seed
+
+    def uniform(self, a, b):
+        self.state = ((self.state & 0xFFFFFFFF) * 4164903690 + (self.state >> 32)) & (2 ** 64 - 1)
+        return a + (self.state & 0xFFFFFFFF) % (b - a)
+
+
+def get_subset(rng, n, k=5):
+    idx = []
+    while len(idx) < k:
+        v = rng.uniform(0, n)
+        if v not in idx:
+            idx.append(v)
+    return idx
+
+
+def update_num_iters(p, ep, model_points, max_iters):
+    p = min(max(p, 0.0), 1.0)
+    ep = min(max(ep, 0.0), 1.0)
+    num = max(1.0 - p, 2.2250738585072014e-308)
+    denom = 1.0 - (1.0 - ep) ** model_points
+    if denom < 2.2250738585072014e-308:
+        return 0
+    num, denom = math.log(num), math.log(denom)
+    if denom >= 0 or -num >= max_iters * (-denom):
+        return max_iters
+    return int(np.rint(num / denom))
+
+
+def sampson(E, q1, q2):
+    x1 = np.concatenate([q1, np.ones((len(q1), 1))], 1)
+    x2 = np.concatenate([q2, np.ones((len(q2), 1))], 1)
+    Ex1 = x1 @ E.T
+    Etx2 = x2 @ E
+    num = (x2 * Ex1).sum(1) ** 2
+    return (num / (Ex1[:, 0] ** 2 + Ex1[:, 1] ** 2 + Etx2[:, 0] ** 2 + Etx2[:, 1] ** 2)).astype(np.float32)
+
+
+# ---- tests --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_five_point_kernel_contains_the_true_essential_matrix(orc, seed):
+    """Nister's solver on five exact correspondences: one of the <= 10 real solutions is [t]x R (up to scale and sign), and every
+    solution satisfies the epipolar constraint on the five points, det E = 0 and 2 E E^T E - tr(E E^T) E = 0."""
+    S = _scene(seed, 5)
+    q1, q2 = _norm(S["p1"]), _norm(S["p2"])
+    Es = np.zeros(90)
+    n = orc.lib.orc_host_five_point(_p(q1, _f64p), _p(q2, _f64p), _p(Es, _f64p))
+    assert 1 <= n <= 10
+    Es = Es[: 9 * n].reshape(n, 3, 3)
+    Etrue = _skew(S["t"]) @ S["R"]
+    assert min(_same_up_to_sign(E, Etrue) for E in Es) < 1e-8
+    x1 = np.concatenate([q1, np.ones((5, 1))], 1)
+    x2 = np.concatenate([q2, np.ones((5, 1))], 1)
+    for E in Es:
+        assert abs(np.linalg.norm(E) - 1) < 1e-12
+        assert np.abs(np.einsum("ni,ij,nj->n", x2, E, x1)).max() < 1e-9
+        assert abs(np.linalg.det(E)) < 1e-9
+        assert np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-8
+
+
+def test_ransac_sample_stream_and_iteration_rule_match_independent_twins(orc):
+    """the 5-subsets the RANSAC draws (cv::RNG((uint64)-1) + getSubset's rejection of repeated indices) and RANSACUpdateNumIters"""
+    for n in (5, 6, 37, 400, 549):
+        got = np.zeros((40, 5), np.int32)
+        orc.lib.orc_host_five_point_samples(n, 40, _p(got, _i32p))
+        rng = CvRNG()
+        want = [get_subset(rng, n) for _ in range(40)]
+        assert got.tolist() == want
+    got = np.zeros((1, 5), np.int32)
+    orc.lib.orc_host_five_point_samples(400, 1, _p(got, _i32p))
+    assert got[0].tolist() == [5, 204, 140, 373, 231]      # golden: first sample of a 400-point problem
+    orc.lib.orc_host_update_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    for ep in (0.0, 0.01, 0.1, 0.3, 0.5, 0.8, 0.95, 1.0):
+        for mx in (1000, 100, 7):
+            assert orc.lib.orc_host_update_num_iters(0.99, ep, 5, mx) == update_num_iters(0.99, ep, 5, mx)
+    assert update_num_iters(0.99, 0.3, 5, 1000) == 25 and update_num_iters(0.99, 0.0, 5, 1000) == 0
+
+
+def test_find_essential_noiseless_all_inliers_one_iteration(orc):
+    """exact correspondences: the first hypothesis already explains every point, RANSACUpdateNumIters(ep = 0) = 0 ends the loop"""
+    S = _scene(11, 300)
+    ok, E, mask, drawn = _find_essential(orc, S["p1"], S["p2"])
+    assert ok and mask.all() and drawn == 1
+    assert _same_up_to_sign(E, _skew(S["t"]) @ S["R"]) < 1e-7
+
+
+@pytest.mark.parametrize("seed,n,frac", [(21, 400, 0.25), (22, 180, 0.1), (23, 549, 0.4)])
+def test_find_essential_ransac_replayed_by_independent_twin(orc, seed, n, frac):
+    """The whole RANSAC loop replayed in numpy: the twin draws the subsets itself, asks the five-point kernel (pinned above) for the
+    models of each subset, scores them with its own Sampson distance (float32, <= thr^2), keeps the best with OpenCV's update
+    rule and adaptive iteration count. Mask, iteration count and E must come out identical; helper threads must not matter."""
+    S = _scene(seed, n, noise_px=0.3, outlier_frac=frac, integer=True)      # integer pixels like the reference's cv::Point (Q12)
+    ok, E, mask, drawn = _find_essential(orc, S["p1"], S["p2"])
+    assert ok
+    q1, q2 = _norm(S["p1"]), _norm(S["p2"])
+    thr = np.float32((1.0 / ((K[0] + K[4]) / 2)) ** 2)
+    rng = CvRNG()
+    niters, it, max_good, best, best_mask = 1000, 0, 0, None, None
+    while it < niters:
+        idx = get_subset(rng, n)
+        it += 1
+        Es = np.zeros(90)
+        nm = orc.lib.orc_host_five_point(_p(np.ascontiguousarray(q1[idx]), _f64p), _p(np.ascontiguousarray(q2[idx]), _f64p), _p(Es, _f64p))
+        for Em in Es[: 9 * nm].reshape(nm, 3, 3):
+            good = sampson(Em, q1, q2) <= thr
+            if good.sum() > max(max_good, 4):
+                max_good, best, best_mask = int(good.sum()), Em.copy(), good.copy()
+                niters = update_num_iters(0.99, (n - max_good) / n, 5, niters)
+    assert drawn == it
+    assert np.array_equal(mask.astype(bool), best_mask)
+    assert np.array_equal(E, best)
+    # sanity of the outcome itself: the consensus set is (almost) the true inlier set and E is close to [t]x R
+    assert (mask.astype(bool) & S["outliers"]).sum() <= 0.02 * n and mask.sum() >= 0.8 * (~S["outliers"]).sum()
+    assert _same_up_to_sign(E, _skew(S["t"]) @ S["R"]) < 0.05
+    for workers in (2, 4, 8):
+        ok2, E2, mask2, drawn2 = _find_essential(orc, S["p1"], S["p2"], workers=workers)
+        assert ok2 and drawn2 == drawn and np.array_equal(E2, E) and np.array_equal(mask2, mask)
+
+
+def test_find_essential_degenerate_inputs(orc):
+    S = _scene(31, 4)
+    ok, E, mask, drawn = _find_essential(orc, S["p1"], S["p2"])
+    assert not ok and not mask.any()
+    S = _scene(32, 5)                  # exactly five points: the kernel's first solution, every point an inlier, no RANSAC
+    ok, E, mask, drawn = _find_essential(orc, S["p1"], S["p2"])
+    assert ok and mask.all() and drawn == 0 and abs(np.linalg.norm(E) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43])
+def test_recover_pose_known_answer(orc, seed):
+    """cv::recoverPose on the exact E: R, unit t with the right sign, every point in front of both cameras, triangulated points
+    proportional to the true ones (the reference divides by the 4th coordinate itself, OpenCVFivePointTri.cpp:42-44)."""
+    S = _scene(seed, 200)
+    E = np.ascontiguousarray((_skew(S["t"]) @ S["R"]).reshape(9))
+    n = len(S["p1"])
+    R = np.zeros(9); t = np.zeros(3)
+    mask = np.ones(n, np.uint8); mask[::7] = 0          # findEssentialMat's mask is AND-ed in
+    tri = np.zeros(4 * n)
+    good = orc.lib.orc_host_recover_pose(_p(E, _f64p), _p(S["p1"], _f64p), _p(S["p2"], _f64p), n, _p(K, _f64p), _p(R, _f64p), _p(t, _f64p),
+                                         _p(mask, _u8p), _p(tri, _f64p))
+    want = np.ones(n, np.uint8); want[::7] = 0
+    assert good == want.sum() and np.array_equal(mask, want)
+    assert np.abs(R.reshape(3, 3) - S["R"]).max() < 1e-9 and np.abs(t - S["t"]).max() < 1e-9
+    Q = tri.reshape(4, n)
+    X = (Q[:3] / Q[3]).T
+    assert np.abs(X - S["X"]).max() < 1e-6 * np.abs(S["X"]).max()
+
+
+def _heuristics_twin(R, t, Rs, ts, scale, j, _R, _t):
+    """OdometryPipeline.cpp:171-208 written from the reference source"""
+    c, s = _R[0, 0], _R[0, 2]
+    yrot = math.acos(c) if s <= 0 else -math.acos(c)                      # OdometryPipeline.h:89-108, flip = false
+    if _t[2] < 0 and yrot < 3.1415 / 8 and abs(_t[2]) > max(abs(_t[0]), abs(_t[1])) and abs(_t[2]) < 2 * scale:
+        return R[j] @ _t + t[j], _R @ R[j], _R, _t, 0
+    return R[j] @ ts[j] + t[j], Rs[j] @ R[j], Rs[j], ts[j], 1
+
+
+def test_motion_heuristics_accept_reject_and_fallback(orc):
+    rng = np.random.default_rng(7)
+    n = 6
+    R = np.stack([_rot(rng.normal(0, 0.2, 3)) for _ in range(n)])
+    t = rng.normal(0, 3, (n, 3))
+    Rs = np.stack([_rot(rng.normal(0, 0.05, 3)) for _ in range(n)])
+    ts = rng.normal(0, 1, (n, 3))
+    cases = [
+        (_rot(np.array([0, 0.05, 0])), np.array([0.02, -0.01, -0.9]), 1.0),     # plain forward motion: accepted
+        (_rot(np.array([0, 0.05, 0])), np.array([0.02, -0.01, 0.9]), 1.0),      # t_z >= 0: rejected
+        (_rot(np.array([0, 0.05, 0])), np.array([1.2, -0.01, -0.9]), 1.0),      # sideways larger than forward: rejected
+        (_rot(np.array([0, 0.05, 0])), np.array([0.0, 0.0, -2.5]), 1.0),        # |t_z| >= 2 * scale: rejected
+        (_rot(np.array([0, 0.05, 0])), np.array([0.0, 0.0, -2.5]), 1.3),        # ... accepted with a larger scale
+        (_rot(np.array([0, 0.5, 0])), np.array([0.0, 0.0, -0.9]), 1.0),         # yaw 0.5 rad: the sign convention of calcYRotation decides
+        (_rot(np.array([0, -0.5, 0])), np.array([0.0, 0.0, -0.9]), 1.0),
+        (_rot(np.array([0, 3.1415 / 8 + 1e-3, 0])), np.array([0.0, 0.0, -0.9]), 1.0),
+        (_rot(np.array([0, -(3.1415 / 8 - 1e-3), 0])), np.array([0.0, 0.0, -0.9]), 1.0),
+        (_rot(np.array([0.3, 0.0, 0.1])), np.array([0.0, -0.89, -0.9]), 1.0),
+    ]
+    seen = set()
+    for j in (0, 3, 5):
+        for _R, _t, scale in cases:
+            Ra, ta, Rr, tr = np.zeros(9), np.zeros(3), np.zeros(9), np.zeros(3)
+            fb = orc.lib.orc_host_motion_heuristics(n, _p(np.ascontiguousarray(R.reshape(-1)), _f64p), _p(np.ascontiguousarray(t.reshape(-1)), _f64p),
+                                                    _p(np.ascontiguousarray(Rs.reshape(-1)), _f64p), _p(np.ascontiguousarray(ts.reshape(-1)), _f64p),
+                                                    C.c_double(scale), j, _p(np.ascontiguousarray(_R.reshape(9)), _f64p), _p(np.ascontiguousarray(_t), _f64p),
+                                                    _p(Ra, _f64p), _p(ta, _f64p), _p(Rr, _f64p), _p(tr, _f64p))
+            wt, wR, wRr, wtr, wfb = _heuristics_twin(R, t, Rs, ts, scale, j, _R, _t)
+            assert fb == wfb
+            np.testing.assert_allclose(ta, wt, rtol=0, atol=1e-14)
+            np.testing.assert_allclose(Ra.reshape(3, 3), wR, rtol=0, atol=1e-14)
+            np.testing.assert_allclose(Rr.reshape(3, 3), wRr, rtol=0, atol=0)
+            np.testing.assert_allclose(tr, wtr, rtol=0, atol=0)
+            seen.add(fb)
+    assert seen == {0, 1}
+    # hand-computed: identity history, pure forward step of 0.8 m -> pose (0, 0, -0.8), kept as relative motion
+    I = np.eye(3).reshape(1, 9)
+    z = np.zeros((1, 3))
+    Ra, ta, Rr, tr = np.zeros(9), np.zeros(3), np.zeros(9), np.zeros(3)
+    fb = orc.lib.orc_host_motion_heuristics(1, _p(I.copy(), _f64p), _p(z.copy(), _f64p), _p(I.copy(), _f64p), _p(z.copy(), _f64p), C.c_double(1.0), 0,
+                                            _p(np.eye(3).reshape(9).copy(), _f64p), _p(np.array([0.0, 0.0, -0.8]), _f64p), _p(Ra, _f64p), _p(ta, _f64p),
+                                            _p(Rr, _f64p), _p(tr, _f64p))
+    assert fb == 0 and ta.tolist() == [0.0, 0.0, -0.8] and tr.tolist() == [0.0, 0.0, -0.8] and np.array_equal(Ra.reshape(3, 3), np.eye(3))
