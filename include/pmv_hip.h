@@ -60,6 +60,14 @@ int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, 
  * time the build with inputs already resident in HBM. */
 int pmv_frames_stage(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, int w, int h);
 int pmv_frames_build(pmv_ctx* ctx, int first_slot, int n);
+/* Streamed ingest (Frame::Frame / Frame::init + the front-end's per-frame load, Frame.cpp:31-42, OdometryPipeline.cpp:212-220):
+ * n tightly packed gray frames in HOST memory (pageable, or pinned / registered: then DMA'ed in place) are copied into slots
+ * first_slot.. by an ingest thread on its own HIP stream, chunk by chunk, each chunk's pyramids built as soon as it lands.
+ * pmv_frames_stream_begin returns at once; until pmv_frames_stream_end, pmv_lk_track / pmv_detect_* on a slot of the range first
+ * make the front-end stream wait for that slot's chunk (nothing else blocks), so tracking starts while later frames are still
+ * on their way. `gray` must stay valid until pmv_frames_stream_end, which joins the ingest thread. One stream per context. */
+int pmv_frames_stream_begin(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, int w, int h);
+int pmv_frames_stream_end(pmv_ctx* ctx);
 /* Debug/parity: copy pyramid level `level` of `slot` (unpadded, tightly packed) back to host. Returns level dims. */
 int pmv_frame_get_level(pmv_ctx* ctx, int slot, int level, uint8_t* out, int* w, int* h);
 int pmv_frame_num_levels(pmv_ctx* ctx, int slot); /* maxLevel actually built (>=0) or <0 */
@@ -149,6 +157,8 @@ int pmv_record_get(pmv_ctx* ctx, int i, void* out, long long capacity);
 int pmv_prof_enable(pmv_ctx* ctx, int on);  /* on != 0: reset counters and start recording; 0: stop */
 int pmv_prof_select(pmv_ctx* ctx, unsigned mask); /* after pmv_prof_enable(1): record only classes whose bit (= id) is set */
 int pmv_prof_kernel_count(void);
+/* k_lk work counters since context creation / last reset: out3 = {LK iterations, (track, level) passes, tracks} */
+int pmv_lk_counters(pmv_ctx* ctx, unsigned long long* out3, int reset);
 const char* pmv_prof_kernel_name(int id);
 int pmv_prof_read(pmv_ctx* ctx, int id, int* launches, double* total_ms, double* max_ms);
 
@@ -170,6 +180,10 @@ typedef struct pmv_pipeline_result pmv_pipeline_result;
 
 int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* params, const double* K9, const double* gt_poses12,
                      pmv_pipeline_result** out);
+/* The same run from n_frames gray frames in HOST memory: pmv_frames_stream_begin(ctx, 0, n_frames, host_frames, w, h), the run
+ * (build_pyramids ignored), pmv_frames_stream_end. Identical results; copies and pyramid builds overlap the tracking. */
+int pmv_pipeline_run_streamed(pmv_ctx* ctx, const pmv_pipeline_params* params, const double* K9, const double* gt_poses12,
+                              const uint8_t* host_frames, pmv_pipeline_result** out);
 void pmv_pipeline_free(pmv_pipeline_result* r);
 /* Same, but the (host-container) teardown runs on a background thread; pmv_pipeline_drain() joins all of them. */
 void pmv_pipeline_release(pmv_pipeline_result* r);

@@ -13,6 +13,7 @@
 //     gradient 1e-10 / parameter 1e-8.  FIXED CHOICES: all sums are sequential in observation order; the reduced system
 //     is solved by dense Cholesky (Ceres uses a sparse Cholesky of the same matrix).
 #include "orc_api.h"
+#include "orc_fast.h"
 #include "orc_math.h"
 #include <cstring>
 
@@ -61,25 +62,38 @@ static inline void huber_rho(double s, double a, double rho[3]) {
     } else { rho[0] = s; rho[1] = 1; rho[2] = 0; }
 }
 
+// Optional worker threads for the residual/Jacobian evaluation (bench.py's cpu_baseline leg: CeresBundleAdjustment.cpp:58
+// num_threads = 4). Observations are independent; the per-observation cost terms are added in observation order afterwards, so
+// the result does not depend on the thread count.
+static Pool* g_ba_pool = nullptr;
+static int g_ba_threads = 1;
+void ba_set_pool(Pool* pool, int threads) { g_ba_pool = pool; g_ba_threads = pool ? std::max(1, threads) : 1; }
+
 // cost = 1/2 sum rho(||r||^2); optionally corrected residuals (2*nobs) and Jacobians (nobs*18: Jc 12, Jp 6)
 static double evaluate(const BAProblem& P, const double* x, double* res, double* J) {
     const double* cams = x; const double* pts = x + 6 * P.nc;
-    double cost = 0;
-    for (int i = 0; i < P.nobs; i++) {
-        double r[2], Jc[12], Jp[6];
-        projection_residual(cams + 6 * P.cam_idx[i], pts + 3 * P.pt_idx[i], P.obs + 2 * i, P.K, r, J ? Jc : nullptr, J ? Jp : nullptr);
-        const double s = r[0] * r[0] + r[1] * r[1];
-        double rho[3];
-        huber_rho(s, P.huber, rho);
-        cost += 0.5 * rho[0];
-        // ceres Corrector: rho'' <= 0 for Huber -> scale residual and Jacobian by sqrt(rho')
-        const double sr = std::sqrt(rho[1]);
-        if (res) { res[2 * i] = r[0] * sr; res[2 * i + 1] = r[1] * sr; }
-        if (J) {
-            for (int k = 0; k < 12; k++) J[i * 18 + k] = Jc[k] * sr;
-            for (int k = 0; k < 6; k++) J[i * 18 + 12 + k] = Jp[k] * sr;
+    std::vector<double> term(P.nobs);
+    auto range = [&](int lo, int hi) {
+        for (int i = lo; i < hi; i++) {
+            double r[2], Jc[12], Jp[6];
+            projection_residual(cams + 6 * P.cam_idx[i], pts + 3 * P.pt_idx[i], P.obs + 2 * i, P.K, r, J ? Jc : nullptr, J ? Jp : nullptr);
+            const double s = r[0] * r[0] + r[1] * r[1];
+            double rho[3];
+            huber_rho(s, P.huber, rho);
+            term[i] = 0.5 * rho[0];
+            // ceres Corrector: rho'' <= 0 for Huber -> scale residual and Jacobian by sqrt(rho')
+            const double sr = std::sqrt(rho[1]);
+            if (res) { res[2 * i] = r[0] * sr; res[2 * i + 1] = r[1] * sr; }
+            if (J) {
+                for (int k = 0; k < 12; k++) J[i * 18 + k] = Jc[k] * sr;
+                for (int k = 0; k < 6; k++) J[i * 18 + 12 + k] = Jp[k] * sr;
+            }
         }
-    }
+    };
+    if (g_ba_pool && g_ba_threads > 1 && P.nobs >= 256) g_ba_pool->parallel_for(P.nobs, g_ba_threads, range);
+    else range(0, P.nobs);
+    double cost = 0;
+    for (int i = 0; i < P.nobs; i++) cost += term[i];
     return cost;
 }
 

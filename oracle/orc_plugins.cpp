@@ -5,6 +5,7 @@
 //   * bench.py times as `cpu_baseline` (kind "port") on the GPU box's host cores, with the reference's threading model
 //     (front-end + back-end threads, LK parallel over tracks).
 #include "orc_api.h"
+#include "orc_fast.h"
 #include "vo_capi_impl.h"
 #include <cstring>
 
@@ -12,15 +13,19 @@ namespace {
 using namespace vo;
 
 struct CpuGftt : GoodFeatureExtractorBase {
+    orc::Pool* pool = nullptr;   // fast mode: the grid cells are independent calls -> side by side (same results)
     void gftt(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out) override {
-        out.clear();
-        std::vector<int> xy((size_t)(max > 0 ? max : 65536) * 2);   // max <= 0: no limit (at most one corner per pixel of a 255x255 cell)
-        for (auto& c : cells) {
-            const int n = orc::gftt_cell(c.host, c.full_w, c.full_h, c.x0, c.y0, c.w, c.h, max, quality, min_distance, xy.data(), nullptr);
-            std::vector<std::pair<int, int>> v;
-            for (int i = 0; i < n; i++) v.push_back({xy[2 * i], xy[2 * i + 1]});
-            out.push_back(v);
-        }
+        out.assign(cells.size(), {});
+        const size_t cap = (size_t)(max > 0 ? max : 65536);   // max <= 0: no limit (at most one corner per pixel of a 255x255 cell)
+        auto work = [&](int lo, int hi) {
+            std::vector<int> xy(cap * 2);
+            for (int k = lo; k < hi; k++) {
+                const ImageView& c = cells[k];
+                const int n = orc::gftt_cell(c.host, c.full_w, c.full_h, c.x0, c.y0, c.w, c.h, max, quality, min_distance, xy.data(), nullptr);
+                for (int i = 0; i < n; i++) out[k].push_back({xy[2 * i], xy[2 * i + 1]});
+            }
+        };
+        if (pool) pool->parallel_for((int)cells.size(), (int)cells.size(), work); else work(0, (int)cells.size());
     }
 };
 struct CpuShiTomasi : ShiTomasiExtractorBase {
@@ -40,8 +45,14 @@ struct CpuShiTomasi : ShiTomasiExtractorBase {
 };
 struct CpuLK : LucasKanadeFMBase {
     int nthreads = 1;
+    orc::Pool* pool = nullptr;   // fast mode (cpu_baseline timing): padded-buffer LK on a persistent pool, bit-identical results
     void pyrlk(const ImageView& prev, const ImageView& next, const float* prev_xy, int n, float* next_xy, uint8_t* status,
                float* err) override {
+        if (pool) {
+            orc::LKParams P;
+            orc::lk_track_fast(prev.host, next.host, prev.full_w, prev.full_h, prev_xy, n, P, next_xy, status, err, pool);
+            return;
+        }
         orc::Image8 a(prev.full_w, prev.full_h), b(next.full_w, next.full_h);
         memcpy(a.d.data(), prev.host, a.d.size());
         memcpy(b.d.data(), next.host, b.d.size());
@@ -72,16 +83,23 @@ extern "C" {
 void* orc_pipeline_run(const vo::PipelineParams* P, const uint8_t* frames, const double* K9, const double* gt_poses12) {
     auto* run = new vo::PipelineRun();
     vo::pipeline_setup(*run, *P, frames, K9, gt_poses12);
+    // reserved bit 0 = "fast": the speed-oriented twins of orc_fast.cpp (bench.py's cpu_baseline); results are bit-identical
+    // (two pools: a Pool serves one caller at a time, and the front-end and back-end threads run concurrently)
+    std::unique_ptr<orc::Pool> pool, ba_pool;
+    if (P->reserved & 1) { pool.reset(new orc::Pool(std::max(0, P->n_threads - 1))); ba_pool.reset(new orc::Pool(3)); }
     vo::BaseFeatureExtractor* ex;
-    if (P->extractor == 1) ex = new CpuShiTomasi(); else ex = new CpuGftt();
+    if (P->extractor == 1) ex = new CpuShiTomasi(); else { auto* g = new CpuGftt(); g->pool = pool.get(); ex = g; }
     run->owned_ex.push_back(ex);
-    auto* lk = new CpuLK(); lk->nthreads = P->n_threads;
+    auto* lk = new CpuLK(); lk->nthreads = P->n_threads; lk->pool = pool.get();
+    // the back-end thread evaluates BA residuals on 4 threads of the same pool (CeresBundleAdjustment.cpp:58)
+    orc::ba_set_pool(ba_pool.get(), 4);
     auto* pnp = new CpuPnP(); pnp->tracker = &run->pipe;
     auto* tri = new vo::FivePointTri(); tri->tracker = &run->pipe; tri->workers = std::max(1, std::min(P->n_threads, 8));
     auto* ba = new CpuBA(); ba->tracker = &run->pipe;
     run->m = lk; run->p = pnp; run->tr = tri; run->b = ba;
     run->pipe.extractor = ex; run->pipe.matcher = lk; run->pipe.pnpsolver = pnp; run->pipe.triangulator = tri; run->pipe.ba = ba;
     vo::pipeline_execute(*run, *P);
+    orc::ba_set_pool(nullptr, 1);
     return run;
 }
 void orc_pipeline_free(void* h) { delete (vo::PipelineRun*)h; }

@@ -34,12 +34,12 @@ class BaSummary(C.Structure):
 # every symbol include/pmv_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
-    "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frame_get_level", "pmv_frame_num_levels",
+    "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates",
     "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
-    "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_prof_kernel_name", "pmv_prof_read",
-    "pmv_pipeline_run", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
+    "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_lk_counters", "pmv_prof_kernel_name", "pmv_prof_read",
+    "pmv_pipeline_run", "pmv_pipeline_run_streamed", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
     "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_stats_count", "pmv_pipeline_get_stats",
 ]
 
@@ -150,6 +150,7 @@ def load_library():
         _lib.pmv_last_error.argtypes = [C.c_void_p]
         if hasattr(_lib, "pmv_pipeline_run"):
             _lib.pmv_pipeline_run.argtypes = [C.c_void_p, C.POINTER(PipelineParams), _f64p, _f64p, C.POINTER(C.c_void_p)]
+            _lib.pmv_pipeline_run_streamed.argtypes = [C.c_void_p, C.POINTER(PipelineParams), _f64p, _f64p, _u8p, C.POINTER(C.c_void_p)]
             _lib.pmv_pipeline_free.argtypes = [C.c_void_p]
             _lib.pmv_pipeline_release.argtypes = [C.c_void_p]
             _lib.pmv_pipeline_release.restype = None
@@ -234,6 +235,16 @@ class Context:
     def frames_stage(self, first_slot, frames):
         f = np.ascontiguousarray(frames, np.uint8)
         self._ck(self.lib.pmv_frames_stage(self.h, first_slot, f.shape[0], _p(f, _u8p), f.shape[2], f.shape[1]))
+
+    def frames_stream_begin(self, first_slot, frames):
+        """start streaming host frames (n, h, w) uint8 into slots first_slot..; `frames` must stay alive until frames_stream_end()"""
+        f = np.ascontiguousarray(frames, np.uint8)
+        self._stream_src = f
+        self._ck(self.lib.pmv_frames_stream_begin(self.h, first_slot, f.shape[0], _p(f, _u8p), f.shape[2], f.shape[1]))
+
+    def frames_stream_end(self):
+        self._ck(self.lib.pmv_frames_stream_end(self.h))
+        self._stream_src = None
 
     def frames_build(self, first_slot, n):
         self._ck(self.lib.pmv_frames_build(self.h, first_slot, n))
@@ -376,6 +387,12 @@ class Context:
     def prof_enable(self, on=True):
         self._ck(self.lib.pmv_prof_enable(self.h, 1 if on else 0))
 
+    def lk_counters(self, reset=False):
+        """(LK iterations, (track, level) passes, tracks) executed by k_lk since the last reset"""
+        out = (C.c_ulonglong * 3)()
+        self._ck(self.lib.pmv_lk_counters(self.h, out, 1 if reset else 0))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def prof_select(self, names):
         """after prof_enable(True): record only the named kernel classes"""
         self.lib.pmv_prof_kernel_name.restype = C.c_char_p
@@ -399,15 +416,21 @@ class Context:
     # ---- whole sequence (OdometryPipeline role) ----
     def pipeline_run(self, n_frames, w, h, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5,
                      ba_iterations=5, extractor=0, threaded=0, build_pyramids=1, want_features=True, n_threads=1, async_free=False,
-                     defer_free=False):
-        """frames 0..n_frames-1 must be staged in slots 0..n_frames-1 (frames_stage); n_threads: host threads that evaluate the
-        five-point RANSAC hypotheses of the triangulator side by side (the results do not depend on it)"""
+                     defer_free=False, host_frames=None):
+        """frames 0..n_frames-1 must be staged in slots 0..n_frames-1 (frames_stage) unless host_frames (n, h, w) uint8 is given:
+        then they are streamed from host memory while the pipeline runs (pmv_pipeline_run_streamed). n_threads: host threads that
+        evaluate the five-point RANSAC hypotheses of the triangulator side by side (the results do not depend on it)"""
         P = PipelineParams(n_frames, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
                            n_threads, build_pyramids)
         Kd = np.ascontiguousarray(K, np.float64).reshape(9)
         gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n_frames, 12)
         out = C.c_void_p()
-        self._ck(self.lib.pmv_pipeline_run(self.h, C.byref(P), _p(Kd, _f64p), _p(gt, _f64p), C.byref(out)))
+        if host_frames is not None:
+            hf = np.ascontiguousarray(host_frames, np.uint8)
+            assert hf.shape == (n_frames, h, w)
+            self._ck(self.lib.pmv_pipeline_run_streamed(self.h, C.byref(P), _p(Kd, _f64p), _p(gt, _f64p), _p(hf, _u8p), C.byref(out)))
+        else:
+            self._ck(self.lib.pmv_pipeline_run(self.h, C.byref(P), _p(Kd, _f64p), _p(gt, _f64p), C.byref(out)))
         # Tearing down the ~10^6 host-container nodes of a long run takes ~40 ms and is not part of the path. defer_free: the
         # caller frees later (result.free()); async_free: a background thread does it (pipeline_drain() joins).
         ok = False

@@ -1549,21 +1549,29 @@ hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double
     const int tiles = A.tiles_r * A.tiles_c;
     // launches: E0 (+ the clear of Yt | Wt), then per iteration C|P (with the decision on the previous step) -> G -> S -> B, then F
     const int clear_blocks = (int)std::min<size_t>(64, ((size_t)A.krows * A.ldw + 4 * BM_T - 1) / (4 * BM_T));
-    hipLaunchKernelGGL(k_bam_eval0, dim3(nbo + clear_blocks), dim3(BM_T), 0, s, A, st2[1], chol_flags, part_cost, nbo);
+    { ProfScope p_(K_BAM_EVAL0, s);
+    hipLaunchKernelGGL(k_bam_eval0, dim3(nbo + clear_blocks), dim3(BM_T), 0, s, A, st2[1], chol_flags, part_cost, nbo); }
     for (int it = 0; it < A.max_iterations; it++) {
         BAGState* sin = st2[it & 1];
         BAGState* sc = st2[(it + 1) & 1];   // the state of this iteration
         int* cf = chol_flags + it;
         if (it == 0) {   // the point kernel needs the camera scales of the C kernel in the first iteration
+            ProfScope p_(K_BAM_CAMPOINT, s);
             hipLaunchKernelGGL(k_bam_campoint, dim3(A.nc), dim3(BM_T), 0, s, A, sc, sc, 0, part4, nbp, cf, A.nc, Ublk, rhsblk, part_gmax);
             hipLaunchKernelGGL(k_bam_campoint, dim3(nbp), dim3(BM_T), 0, s, A, sc, sc, 0, part4, nbp, cf, 0, Ublk, rhsblk, part_gmax);
-        } else
+        } else {
+            ProfScope p_(K_BAM_CAMPOINT, s);
             hipLaunchKernelGGL(k_bam_campoint, dim3(A.nc + nbp), dim3(BM_T), 0, s, A, sin, sc, 1, part4, nbp, cf, A.nc, Ublk, rhsblk, part_gmax);
-        hipLaunchKernelGGL(k_bam_gemm, dim3(tiles * BG_H), dim3(64 * BG_W), 0, s, A, sc);
-        hipLaunchKernelGGL(k_bam_solve, dim3(1), dim3(BM_T), shm, s, A, sc, cf, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot);
-        hipLaunchKernelGGL(k_bam_backsub, dim3(nbp), dim3(BM_T), 0, s, A, sc, candrot, tmp3, part4);
+        }
+        { ProfScope p_(K_BAM_GEMM, s);
+        hipLaunchKernelGGL(k_bam_gemm, dim3(tiles * BG_H), dim3(64 * BG_W), 0, s, A, sc); }
+        { ProfScope p_(K_BAM_SOLVE, s);
+        hipLaunchKernelGGL(k_bam_solve, dim3(1), dim3(BM_T), shm, s, A, sc, cf, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot); }
+        { ProfScope p_(K_BAM_BACKSUB, s);
+        hipLaunchKernelGGL(k_bam_backsub, dim3(nbp), dim3(BM_T), 0, s, A, sc, candrot, tmp3, part4); }
     }
-    hipLaunchKernelGGL(k_bam_finish, dim3(1), dim3(BM_T), 0, s, A, st2[A.max_iterations & 1], part4, nbp);
+    { ProfScope p_(K_BAM_FINISH, s);
+    hipLaunchKernelGGL(k_bam_finish, dim3(1), dim3(BM_T), 0, s, A, st2[A.max_iterations & 1], part4, nbp); }
     return hipGetLastError();
 }
 

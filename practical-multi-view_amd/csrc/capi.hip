@@ -87,6 +87,8 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     CK(hipHostGetDevicePointer((void**)&c->dm_out_xy, c->h_out_xy, 0));
     CK(hipHostGetDevicePointer((void**)&c->dm_status, c->h_status, 0));
     CK(hipHostGetDevicePointer((void**)&c->dm_err, c->h_err, 0));
+    CK(hipMalloc(&c->d_lk_counters, 32));
+    CK(hipMemset(c->d_lk_counters, 0, 32));
     CK(hipMalloc(&c->d_cells, MAX_CELLS * 16));
     CK(hipMalloc(&c->d_eig, (size_t)MAX_CELLS * CELL_PIX * sizeof(double)));   // shared by GFTT (f32) and ShiTomasi (f64)
     CK(hipMalloc(&c->d_cellmax, MAX_CELLS * 8));
@@ -115,11 +117,13 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
 void pmv_ctx_destroy(pmv_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    ingest_destroy(c);
     if (c->s_front) hipStreamSynchronize(c->s_front);
     if (c->s_back) hipStreamSynchronize(c->s_back);
     backend_destroy(c);
     c->prof.destroy();
     if (c->d_lk_stamps) hipFree(c->d_lk_stamps);
+    if (c->d_lk_counters) hipFree(c->d_lk_counters);
     hipFree(c->d_slots); hipFree(c->d_prev_xy); hipFree(c->d_out_xy); hipFree(c->d_status); hipFree(c->d_err);
     hipHostFree(c->h_prev_xy); hipHostFree(c->h_out_xy); hipHostFree(c->h_status); hipHostFree(c->h_err);
     hipFree(c->d_cells); hipFree(c->d_eig); hipFree(c->d_cellmax); hipFree(c->d_det_xy); hipFree(c->d_det_score);
@@ -140,19 +144,22 @@ int pmv_sync(pmv_ctx* ctx) {
     return PMV_OK;
 }
 
-static int build_levels(pmv_ctx* ctx, int first_slot, int n, const PyrLayout& L) {
-    CKC(launch_pad_level0(ctx->s_front, ctx->d_slots, L, first_slot, n));
-    for (int l = 1; l < L.n_levels; l++) CKC(launch_pyrdown(ctx->s_front, ctx->d_slots, L, l, first_slot, n));
+}  // extern "C"
+int pmv::build_levels_on(pmv_ctx* ctx, hipStream_t stream, int first_slot, int n, const PyrLayout& L) {
+    CKC(launch_pad_level0(stream, ctx->d_slots, L, first_slot, n));
+    for (int l = 1; l < L.n_levels; l++) CKC(launch_pyrdown(stream, ctx->d_slots, L, l, first_slot, n));
     return PMV_OK;
 }
+static int build_levels(pmv_ctx* ctx, int first_slot, int n, const PyrLayout& L) { return build_levels_on(ctx, ctx->s_front, first_slot, n, L); }
 
 // NOTE: slots are addressed with the CAPACITY slot size (ctx->cap.slot_bytes); a frame smaller than max_w x max_h
 // uses its own level geometry inside the slot but the same slot pitch.
-static PyrLayout layout_for(pmv_ctx* ctx, int w, int h) {
+PyrLayout pmv::layout_for(pmv_ctx* ctx, int w, int h) {
     PyrLayout L = make_layout(w, h);
     L.slot_bytes = ctx->cap.slot_bytes;
     return L;
 }
+extern "C" {
 
 int pmv_frames_stage(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, int w, int h) {
     REQ(ctx && gray, PMV_ERR_INVALID, "pmv_frames_stage: null argument");
@@ -229,6 +236,7 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     REQ(ctx && (n == 0 || (prev_xy && out_xy && out_status && out_err)), PMV_ERR_INVALID, "pmv_lk_track: null argument");
     REQ(n >= 0 && n <= ctx->max_tracks, PMV_ERR_CAPACITY, "pmv_lk_track: n=%d exceeds max_tracks=%d", n, ctx->max_tracks);
     REQ(prev_slot >= 0 && prev_slot < ctx->n_slots && next_slot >= 0 && next_slot < ctx->n_slots, PMV_ERR_CAPACITY, "pmv_lk_track: slot out of range");
+    if (ctx->ingest) { int rc_ = ingest_require(ctx, prev_slot > next_slot ? prev_slot : next_slot); if (rc_) return rc_; }
     const PyrLayout& L = ctx->slot_layout[prev_slot];
     const PyrLayout& L2 = ctx->slot_layout[next_slot];
     REQ(L.n_levels > 0 && L2.n_levels > 0, PMV_ERR_INVALID, "pmv_lk_track: slot has no pyramid");
@@ -258,6 +266,7 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f;
     if (!ctx->d_lk_stamps && getenv("PMV_LK_STAMPS")) { CKC(hipMalloc(&ctx->d_lk_stamps, 16 * 8)); CKC(hipMemset(ctx->d_lk_stamps, 0, 16 * 8)); }
     P.stamps = ctx->d_lk_stamps;
+    P.counters = ctx->d_lk_counters;
     CKC(launch_lk(ctx->s_front, ctx->d_slots + (size_t)prev_slot * L.slot_bytes, ctx->d_slots + (size_t)next_slot * L.slot_bytes,
                   L, ctx->d_prev_xy, (const int*)(ctx->d_prev_xy + (size_t)2 * n), nb, n, P, ctx->dm_out_xy, ctx->dm_status, ctx->dm_err));
     CKC(hipStreamSynchronize(ctx->s_front));   // the kernel wrote positions / status / err straight into mapped pinned memory
@@ -272,6 +281,7 @@ static int check_cells(pmv_ctx* ctx, int slot, const int* cells, int n_cells, in
     REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "detect: slot out of range");
     REQ(n_cells >= 1 && n_cells <= MAX_CELLS, PMV_ERR_CAPACITY, "detect: n_cells=%d (max %d)", n_cells, MAX_CELLS);
     REQ(max_per_cell >= 1 && max_per_cell <= MAX_PER_CELL, PMV_ERR_CAPACITY, "detect: max_per_cell=%d (max %d)", max_per_cell, MAX_PER_CELL);
+    if (ctx->ingest) { int rc_ = ingest_require(ctx, slot); if (rc_) return rc_; }
     const PyrLayout& L = ctx->slot_layout[slot];
     REQ(L.n_levels > 0, PMV_ERR_INVALID, "detect: slot %d has no frame", slot);
     for (int i = 0; i < n_cells; i++) {
@@ -349,6 +359,7 @@ int pmv_prof_enable(pmv_ctx* ctx, int on) {
     if (on) for (int i = 0; i < K_COUNT; i++) { ctx->prof.used[i] = 0; ctx->prof.dropped[i] = 0; }
     ctx->prof.enabled = on != 0;
     ctx->prof.mask = ~0u;
+    ctx->prof.chain_detail = false;
     return PMV_OK;
 }
 // restrict recording to the classes whose bit is set (events cost host time and a queue barrier each: the timed region of the
@@ -356,6 +367,7 @@ int pmv_prof_enable(pmv_ctx* ctx, int on) {
 int pmv_prof_select(pmv_ctx* ctx, unsigned mask) {
     REQ(ctx, PMV_ERR_INVALID, "null ctx");
     ctx->prof.mask = mask;
+    ctx->prof.chain_detail = (mask >> K_BAM_EVAL0) != 0 && mask != ~0u;
     return PMV_OK;
 }
 // diagnostic: phase timers of k_lk for track 0 (PMV_LK_STAMPS=1): [0] level entry, [1] I tile, [2] Scharr, [3] samples + A, [4] iterations
@@ -367,6 +379,17 @@ int pmv_debug_lk_stamps(pmv_ctx* ctx, unsigned long long* out16) {
     CKC(hipSetDevice(ctx->device));
     CKC(hipStreamSynchronize(ctx->s_front));
     CKC(hipMemcpy(out16, ctx->d_lk_stamps, 16 * 8, hipMemcpyDeviceToHost));
+    return PMV_OK;
+}
+// work counters of k_lk accumulated since the context was created or since the last reset: [0] LK iterations executed, [1] (track,
+// level) pairs that entered the iteration loop, [2] tracks. bench.py turns them into SURVEY.md §8(d)'s OPS_lk = sum over tracks and
+// levels of 1024 * (40 + 14 * iterations).
+int pmv_lk_counters(pmv_ctx* ctx, unsigned long long* out3, int reset) {
+    REQ(ctx && out3, PMV_ERR_INVALID, "null argument");
+    CKC(hipSetDevice(ctx->device));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    CKC(hipMemcpy(out3, ctx->d_lk_counters, 24, hipMemcpyDeviceToHost));
+    if (reset) CKC(hipMemset(ctx->d_lk_counters, 0, 32));
     return PMV_OK;
 }
 int pmv_prof_kernel_count(void) { return K_COUNT; }

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
     float outx = 0.f, outy = 0.f, err = 0.f;
     int status = 1;
     int slot = 0;
+    int n_iter = 0, n_lev = 0;   // work counters for the roofline's measured OPS_lk
     const int ml = L.n_levels - 1;
     unsigned long long t_prev = __builtin_readcyclecounter();
 #define LSTAMP(k) do { if (P.stamps && t == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); P.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
         float pdx = 0.f, pdy = 0.f;
         int tx0 = 0, ty0 = 0;
         bool have_tile = false;
+        n_lev++;
 
         for (int j = 0; j < P.max_iter; j++) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nx += dx; ny += dy;
             outx = nx + half; outy = ny + half;
+            n_iter++;
             if (P.stamps && t == 0 && tid == 0) P.stamps[8] += 1;
             if ((double)dx * dx + (double)dy * dy <= P.eps2d) break;
             if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
         out_xy[2 * t] = outx; out_xy[2 * t + 1] = outy;
         out_status[t] = (uint8_t)status;
         out_err[t] = err;
+        if (P.counters) { atomicAdd(&P.counters[0], (unsigned long long)n_iter); atomicAdd(&P.counters[1], (unsigned long long)n_lev); atomicAdd(&P.counters[2], 1ull); }
     }
 }
 

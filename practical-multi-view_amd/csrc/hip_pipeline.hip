@@ -96,6 +96,23 @@ struct pmv_pipeline_result { vo::PipelineRun run; };
 
 extern "C" {
 
+// Same run from HOST frames (n_frames * w * h gray bytes, pageable or pinned): the frames are streamed into slots 0..n_frames-1 by
+// the ingest thread (ingest.hip) while the pipeline is already tracking the first ones. Results are identical to
+// pmv_frames_stage + pmv_pipeline_run(build_pyramids = 1).
+int pmv_pipeline_run_streamed(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K9, const double* gt_poses12,
+                              const uint8_t* host_frames, pmv_pipeline_result** out) {
+    if (!ctx || !P || !host_frames) { pmv::set_err(ctx, "pmv_pipeline_run_streamed: null argument"); return PMV_ERR_INVALID; }
+    if (P->n_frames > ctx->n_slots) { pmv::set_err(ctx, "pmv_pipeline_run_streamed: n_frames=%d exceeds the %d frame slots", P->n_frames, ctx->n_slots); return PMV_ERR_CAPACITY; }
+    int rc = pmv_frames_stream_begin(ctx, 0, P->n_frames, host_frames, P->w, P->h);
+    if (rc != PMV_OK) return rc;
+    pmv_pipeline_params Q = *P;
+    Q.build_pyramids = 0;   // the ingest stream builds them chunk by chunk
+    rc = pmv_pipeline_run(ctx, &Q, K9, gt_poses12, out);
+    const int rc2 = pmv_frames_stream_end(ctx);   // joins the ingest thread (also after a failed run: the source buffer is the caller's)
+    if (rc == PMV_OK && rc2 != PMV_OK) { pmv_pipeline_free(*out); *out = nullptr; return rc2; }
+    return rc;
+}
+
 int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K9, const double* gt_poses12,
                      pmv_pipeline_result** out) {
     if (!ctx || !P || !K9 || !gt_poses12 || !out) { pmv::set_err(ctx, "pmv_pipeline_run: null argument"); return PMV_ERR_INVALID; }

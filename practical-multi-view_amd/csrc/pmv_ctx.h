@@ -6,6 +6,7 @@
 #include <vector>
 
 namespace pmv {
+struct Ingest;                      // streamed frame ingest (ingest.hip)
 constexpr int MAX_CELLS = 64;       // 1920x1080 -> 8x5 = 40 cells of 255x255
 constexpr int MAX_PER_CELL = 4096;    // also the capacity of an "unlimited" (max_per_cell <= 0) goodFeaturesToTrack call
 struct BackendBuffers;              // PnP / BA device workspaces (backend.hip)
@@ -35,6 +36,7 @@ struct pmv_ctx {
     float *dm_out_xy = nullptr, *dm_err = nullptr;   // device aliases of the mapped pinned result buffers
     uint8_t* dm_status = nullptr;
     unsigned long long* d_lk_stamps = nullptr;   // diagnostic (PMV_LK_STAMPS=1)
+    unsigned long long* d_lk_counters = nullptr; // 4 x u64 work counters (iterations, level passes, tracks), see pmv_lk_counters
     // detectors
     int* d_cells = nullptr;
     double* d_eig = nullptr;
@@ -44,6 +46,7 @@ struct pmv_ctx {
     int *h_det_xy = nullptr, *h_det_count = nullptr;
     double* h_det_score = nullptr;
     pmv::BackendBuffers* be = nullptr;
+    pmv::Ingest* ingest = nullptr;      // non-null while a pmv_frames_stream_begin .. _end bracket is open
     pmv::Profiler prof;
     pmv_call_log log;
     char err[512] = "";
@@ -54,6 +57,12 @@ void set_err(pmv_ctx* c, const char* fmt, ...);
 PyrLayout make_layout(int w, int h);
 int backend_create(pmv_ctx* c);     // allocates PnP/BA workspaces
 void backend_destroy(pmv_ctx* c);
+// pyramid levels of `n` consecutive slots with identical geometry L, on `stream` (pmv_frames_build and the ingest thread)
+int build_levels_on(pmv_ctx* ctx, hipStream_t stream, int first_slot, int n, const PyrLayout& L);
+PyrLayout layout_for(pmv_ctx* ctx, int w, int h);
+// streamed ingest: make the front-end stream wait until `slot` has been copied and its pyramid built (no-op without a stream)
+int ingest_require(pmv_ctx* ctx, int slot);
+void ingest_destroy(pmv_ctx* ctx);
 hipError_t frontend_prepare_device();   // per-device kernel attributes (LDS opt-in), called with the context's device current
 hipError_t backend_prepare_device();
 }

@@ -99,6 +99,7 @@ struct LKParams {
     double eps2d;     // epsilon^2 = 1e-4
     float min_eig;    // 1e-4
     unsigned long long* stamps;   // optional (diagnostic): 16 shader-clock phase timers accumulated by the block of track 0
+    unsigned long long* counters; // [0] += LK iterations executed (all levels), [1] += (track, level) pairs that iterated, [2] += tracks
 };
 
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n);

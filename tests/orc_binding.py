@@ -48,6 +48,28 @@ class Oracle:
                                    C.c_double(eps), C.c_float(min_eig), _p(out, _f32p), _p(st, _u8p), _p(err, _f32p))
         return out, st, err, lv
 
+    def lk_track_fast(self, prev, nxt, pts, nthreads=1):
+        """the speed-oriented twin (orc_fast.cpp): must equal lk_track bit for bit"""
+        prev = np.ascontiguousarray(prev, np.uint8)
+        nxt = np.ascontiguousarray(nxt, np.uint8)
+        p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        n = p.shape[0]
+        out = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        h, w = prev.shape
+        rc = self.lib.orc_lk_track_fast(_p(prev, _u8p), _p(nxt, _u8p), w, h, _p(p, _f32p), n, 32, 4, 30, C.c_double(0.01), C.c_float(1e-4),
+                                        _p(out, _f32p), _p(st, _u8p), _p(err, _f32p), nthreads)
+        assert rc == 0
+        return out, st, err
+
+    def pyr_down_fast(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self.lib.orc_pyr_down_fast(_p(img, _u8p), w, h, _p(out, _u8p))
+        return out
+
     def gftt_cell(self, img, cell, max_corners, quality=0.01, min_dist=5.0, want_eig=False):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
@@ -116,9 +138,11 @@ class PipelineResult:
 
 
 def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5, ba_iterations=5,
-                 extractor=0, threaded=0, n_threads=1):
+                 extractor=0, threaded=0, n_threads=1, fast=False, lib=None):
+    """the oracle pipeline; fast=True: the speed-oriented twins (orc_fast.cpp; identical results), lib: another build of the
+    same sources (bench.py times oracle/liborc_fast.so, built -O3 -march=native on the machine it runs on)"""
     o = load()
-    lib = o.lib
+    lib = lib or o.lib
     lib.orc_pipeline_run.restype = C.c_void_p
     for f in ("orc_pipeline_free", "orc_pipeline_num_poses", "orc_pipeline_get_poses", "orc_pipeline_num_frames",
               "orc_pipeline_frame_feature_count", "orc_pipeline_get_frame_features", "orc_pipeline_get_stats"):
@@ -129,7 +153,7 @@ def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, b
     frames = np.ascontiguousarray(frames, np.uint8)
     n, h, w = frames.shape
     P = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
-                       n_threads, 0)
+                       n_threads, 1 if fast else 0)
     Kd = np.ascontiguousarray(K, np.float64).reshape(9)
     gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n, 12)
     lib.orc_pipeline_run.argtypes = [C.POINTER(PipelineParams), _u8p, _f64p, _f64p]

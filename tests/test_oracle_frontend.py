@@ -100,6 +100,35 @@ def test_lk_status_rules(orc):
     assert len(st) == 0
 
 
+@pytest.mark.parametrize("shape", [(370, 1226), (47, 156), (33, 40), (101, 77), (64, 35)])
+def test_fast_pyr_down_twin_is_bit_identical(orc, shape):
+    img = np.random.default_rng(shape[0]).integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(orc.pyr_down_fast(img), orc.pyr_down(img))
+
+
+def test_fast_lk_twin_is_bit_identical(orc):
+    """orc_fast.cpp (padded buffers, vectorisable row loops, thread pool) is the cpu_baseline's LK: same positions, status
+    and err as the plain restatement, for interior, border, outside, flat and non-converging tracks, any thread count."""
+    rng = np.random.default_rng(11)
+    for (h, w), seed in (((240, 400), 3), ((120, 200), 5), ((70, 66), 9)):
+        a = _texture(h, w, seed)
+        b = np.roll(np.roll(a, -3, 0), 4, 1)
+        b[: h // 3] = rng.integers(0, 256, (h // 3, w), dtype=np.uint8)           # a third of the image unrelated: non-convergence
+        pts = np.concatenate([rng.uniform(-45, max(w, h) + 45, (300, 2)), [[0, 0], [w - 1, h - 1], [-32.4, 5], [w - 0.6, h - 0.6], [3.5, h + 31.4]]]).astype(np.float32)
+        ref = orc.lk_track(a, b, pts)
+        for nt in (1, 3, 8):
+            got = orc.lk_track_fast(a, b, pts, nt)
+            for x, y in zip(ref[:3], got):
+                assert np.array_equal(x, y)
+        flat = np.full_like(a, 90)
+        ref = orc.lk_track(flat, b, pts)
+        got = orc.lk_track_fast(flat, b, pts, 2)
+        for x, y in zip(ref[:3], got):
+            assert np.array_equal(x, y)
+    got = orc.lk_track_fast(a, b, np.zeros((0, 2), np.float32), 2)
+    assert len(got[1]) == 0
+
+
 def _corner_image(h, w, step=24):
     img = np.full((h, w), 40, np.uint8)
     for y in range(10, h - 10, step):

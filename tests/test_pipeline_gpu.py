@@ -201,3 +201,38 @@ def test_config5_eight_sequences_sharded_one_per_rank(pmv, gpu_ctx_factory):
         o = ob.run_pipeline(frames, K, gt, threaded=1, n_threads=8)
         print(f"sequence {sid} ({lengths[sid]} frames):", end=" ")
         _compare(single[sid], o, 1e-6, min_tight=min(MIN_TIGHT, len(o.poses)))
+
+
+def test_streamed_ingest_is_bit_identical_to_staged_frames(pmv, gpu_ctx_factory):
+    """frames handed over in HOST memory and streamed into HBM chunk by chunk (ingest thread, third stream, pyramids
+    per chunk) while the pipeline is already tracking give the same features and poses as pmv_frames_stage + a run with all
+    pyramids built up front - from pageable memory (pinned ring) and from pinned memory (DMA in place), threaded and sequential,
+    also when the frame count is not a multiple of the chunk size and when the context is reused."""
+    cfg, n = K00, 75      # 4 full chunks of 16 + 11
+    frames, poses = pmv.synth_sequence(1002, 0, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16)
+    K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096)
+    ctx.frames_stage(0, frames)
+    ref = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1, n_threads=4)
+    ctx2 = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096)
+    for threaded in (1, 0, 1):
+        got = ctx2.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=threaded, n_threads=4, host_frames=frames)
+        assert np.array_equal(got.poses, ref.poses)
+        for a, b in zip(got.features, ref.features):
+            assert np.array_equal(a, b)
+    # pinned source: torch is only used here to get page-locked host memory
+    import torch
+    pinned = torch.empty((n, cfg["h"], cfg["w"]), dtype=torch.uint8).pin_memory()
+    pinned.numpy()[:] = frames
+    got = ctx2.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1, n_threads=4, host_frames=pinned.numpy())
+    assert np.array_equal(got.poses, ref.poses)
+    # the plain C-ABI calls on a streaming context: LK between two late slots waits for their chunk and matches the staged context
+    ctx2.frames_stream_begin(0, frames)
+    pts = np.stack(np.meshgrid(np.arange(100, 1100, 90), np.arange(60, 330, 70)), -1).reshape(-1, 2).astype(np.float32)
+    a = ctx2.lk_track(n - 2, n - 1, pts)
+    ctx2.frames_stream_end()
+    b = ctx.lk_track(n - 2, n - 1, pts)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for l in range(ctx.num_levels(n - 1) + 1):
+        assert np.array_equal(ctx2.get_level(n - 1, l, cfg["w"], cfg["h"]), ctx.get_level(n - 1, l, cfg["w"], cfg["h"]))
