@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates",
     "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
     "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_lk_counters", "pmv_prof_kernel_name", "pmv_prof_read",
-    "pmv_pipeline_run", "pmv_pipeline_run_streamed", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
+    "pmv_pipeline_run", "pmv_pipeline_run_streamed", "pmv_pipeline_run_batch", "pmv_batch_stats", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
     "pmv_pipeline_frame_feature_count", "pmv_pipeline_get_frame_features", "pmv_pipeline_stats_count", "pmv_pipeline_get_stats",
 ]
 
@@ -446,6 +446,43 @@ class Context:
         if defer_free:
             r._deferred = (self.lib, out)
         return r
+
+    def pipeline_run_batch(self, seqs, w, h, K, min_tracked=400, tol=150, init_frames=5, bundle_size=5, ba_iterations=5, extractor=0,
+                           build_pyramids=1, want_features=True, defer_free=False):
+        """B independent sequences through batched launches (pmv_pipeline_run_batch). seqs: list of (first_slot, n_frames, gt_poses);
+        the frames must be staged in slots first_slot..first_slot+n_frames-1. K: 9 values shared by all, or (B, 9). Returns one
+        PipelineResult per sequence (bit-identical to pipeline_run on the same sequence)."""
+        B = len(seqs)
+        params = (PipelineParams * B)()
+        gts = []
+        gt_ptrs = (_f64p * B)()
+        first = (C.c_int * B)()
+        Kd = np.ascontiguousarray(np.broadcast_to(np.asarray(K, np.float64).reshape(-1, 9), (B, 9)))
+        for b, (fs, n, gt) in enumerate(seqs):
+            params[b] = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, 1, 1, build_pyramids)
+            g = np.ascontiguousarray(gt, np.float64).reshape(n, 12)
+            gts.append(g)
+            gt_ptrs[b] = _p(g, _f64p)
+            first[b] = fs
+        outs = (C.c_void_p * B)()
+        self.lib.pmv_pipeline_run_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(PipelineParams), _f64p, C.POINTER(_f64p), _i32p, C.POINTER(C.c_void_p)]
+        self._ck(self.lib.pmv_pipeline_run_batch(self.h, B, params, _p(Kd, _f64p), gt_ptrs, first, outs))
+        res = []
+        for b in range(B):
+            hnd = C.c_void_p(outs[b])
+            r = PipelineResult(self.lib, hnd, want_features)
+            if defer_free:
+                r._deferred = (self.lib, hnd)
+            else:
+                self.lib.pmv_pipeline_free(hnd)
+            res.append(r)
+        return res
+
+    def batch_stats(self):
+        """{front launches, front requests, back launches, back requests} of the batch engine's two combiners"""
+        out = (C.c_longlong * 4)()
+        self.lib.pmv_batch_stats(self.h, out)
+        return dict(front_launches=int(out[0]), front_requests=int(out[1]), back_launches=int(out[2]), back_requests=int(out[3]))
 
     def pipeline_drain(self):
         self.lib.pmv_pipeline_drain()

@@ -9,44 +9,11 @@
 
 namespace pmv {
 
-constexpr int MAX_HYP = 1024;
-
-struct BackendBuffers {
-    // BA problem
-    double *d_cams = nullptr, *d_pts = nullptr, *d_obs = nullptr, *d_K = nullptr;
-    int *d_cam_idx = nullptr, *d_pt_idx = nullptr, *d_pobs_start = nullptr, *d_pobs_list = nullptr, *d_cobs_start = nullptr, *d_cobs_list = nullptr;
-    // BA workspaces
-    double *d_x = nullptr, *d_cand = nullptr, *d_scale = nullptr, *d_diag = nullptr, *d_D2 = nullptr, *d_step = nullptr, *d_res = nullptr,
-           *d_J = nullptr, *d_Einv = nullptr, *d_gp = nullptr, *d_Yd = nullptr, *d_Wd = nullptr, *d_S = nullptr, *d_rhs = nullptr,
-           *d_Gpart = nullptr, *d_summary = nullptr;
-    size_t ydwd_elems = 0, gpart_elems = 0;
-    unsigned long long* d_stamps = nullptr;
-    void* d_bastate = nullptr;
-    double* d_bapart = nullptr;
-    char *d_tri_in = nullptr, *d_tri_out = nullptr;
-    char* d_h_stage = nullptr;   // device address of the pinned staging block: result blocks are written straight into it
-    size_t tri_in_bytes = 0, tri_out_bytes = 0;
-    // single-copy transfers: one pinned staging block and one device block per direction
-    void* h_stage = nullptr;
-    size_t h_stage_bytes = 0;
-    char* d_ba_io = nullptr;   // [summary 8 | cams | pts | obs | K | cam_idx | pt_idx | pobs_start | pobs_list | cobs_start | cobs_list]
-    size_t ba_io_bytes = 0;
-    char* d_pnp_in = nullptr;  // [K 10 doubles | obj | img | samples]
-    char* d_pnp_out = nullptr; // [rt 6 doubles | info 4 ints | inliers]
-    size_t pnp_in_bytes = 0, pnp_out_bytes = 0;
-    // PnP
-    float *d_obj = nullptr, *d_img = nullptr;
-    int *d_samples = nullptr, *d_counts = nullptr, *d_inliers = nullptr, *d_info = nullptr;
-    double *d_models = nullptr, *d_rt = nullptr, *d_Kp = nullptr;
-    uint8_t* d_masks = nullptr;
-};
-
-constexpr size_t PNP_HDR = 384;   // bytes: K (10 doubles) + 33 powers of ten + padding
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-int backend_create(pmv_ctx* c) {
+int backend_alloc(pmv_ctx* c, BackendBuffers** out) {
     BackendBuffers* b = new BackendBuffers();
-    c->be = b;
+    *out = b;
     const size_t nc = (size_t)std::max(c->max_ba_cams, 1), np = (size_t)std::max(c->max_ba_points, 1), no = (size_t)std::max(c->max_ba_obs, 1);
     const size_t n = 6 * nc + 3 * np, m = 6 * nc;
     const size_t ldw = (size_t)round_up((int)m + 1, 16), krows = (size_t)round_up((int)(3 * np), 16);
@@ -104,19 +71,20 @@ int backend_create(pmv_ctx* c) {
 #undef CKB
     return PMV_OK;
 }
+int backend_create(pmv_ctx* c) { return backend_alloc(c, &c->be); }
 
-void backend_destroy(pmv_ctx* c) {
-    BackendBuffers* b = c->be;
+void backend_free(BackendBuffers* b) {
     if (!b) return;
     void* ptrs[] = {b->d_cams, b->d_pts, b->d_obs, b->d_K, b->d_cam_idx, b->d_pt_idx, b->d_pobs_start, b->d_pobs_list, b->d_cobs_start,
                     b->d_cobs_list, b->d_x, b->d_cand, b->d_scale, b->d_diag, b->d_D2, b->d_step, b->d_res, b->d_J, b->d_Einv, b->d_gp,
                     b->d_Yd, b->d_Wd, b->d_S, b->d_rhs, b->d_Gpart, b->d_summary, b->d_obj, b->d_img, b->d_samples, b->d_counts,
                     b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out, b->d_bastate, b->d_bapart, b->d_tri_in, b->d_tri_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (b->d_stamps) (void)hipFree(b->d_stamps);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     delete b;
-    c->be = nullptr;
 }
+void backend_destroy(pmv_ctx* c) { backend_free(c->be); c->be = nullptr; }
 
 // cv::RNG (multiply-with-carry) and RANSACPointSetRegistrator::getSubset (5 distinct indices)
 struct CvRNG {
@@ -135,8 +103,12 @@ using namespace pmv;
 
 extern "C" {
 
-int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec,
-                   int iterations, float reproj_err, double confidence, int* out_inliers, int* out_n_inliers) {
+}  // extern "C"
+
+// ---- PnP: prepare (host slab + device problem record) / finish (results out of the pinned block), shared by the single call
+// and by the batch engine (several sequences' calls in one launch) ------------------------------------------------------------
+int pmv::pnp_check(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec, int iterations,
+                   double confidence, int* out_inliers, int* out_n_inliers) {
     REQ(ctx && obj_xyz && img_xy && K && rvec && tvec && out_inliers && out_n_inliers, PMV_ERR_INVALID, "pmv_pnp_ransac: null argument");
     *out_n_inliers = 0;
     REQ(m <= ctx->max_tracks, PMV_ERR_CAPACITY, "pmv_pnp_ransac: m=%d exceeds max_tracks=%d", m, ctx->max_tracks);
@@ -145,18 +117,13 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     REQ(m >= 6, PMV_ERR_DEGENERATE, "pmv_pnp_ransac: %d correspondences (need >= 6)", m);
     REQ(iterations >= 1 && iterations <= MAX_HYP, PMV_ERR_CAPACITY, "pmv_pnp_ransac: iterations=%d (1..%d)", iterations, MAX_HYP);
     REQ(confidence > 0 && confidence < 1, PMV_ERR_INVALID, "pmv_pnp_ransac: confidence must be in (0,1)");
-    tl_prof = &ctx->prof;
-    CKC(hipSetDevice(ctx->device));
-    if (const char* dump = getenv("PMV_DUMP_PNP")) {   // debug: append the inputs of every call to a file
-        if (FILE* f = fopen(dump, "ab")) {
-            fwrite(&m, 4, 1, f); fwrite(obj_xyz, 12, m, f); fwrite(img_xy, 8, m, f); fwrite(K, 8, 9, f); fwrite(rvec, 8, 3, f); fwrite(tvec, 8, 3, f);
-            fclose(f);
-        }
-    }
-    BackendBuffers* b = ctx->be;
-    hipStream_t s = ctx->s_back;
+    return PMV_OK;
+}
+// packs [K 10 doubles, 10^k for k = -16..16 (CvLevMarq's lambda) | obj 3m floats | img 2m floats | samples 5*iterations ints] into b's
+// pinned block and describes the problem with b's device buffers; *in_bytes = bytes to copy h_stage -> d_pnp_in
+void pmv::pnp_prepare(BackendBuffers* b, const float* obj_xyz, const float* img_xy, int m, const double* K, int iterations, float reproj_err,
+                      double confidence, PnPProblem* P, size_t* in_bytes_out) {
     char* hs = (char*)b->h_stage;
-    // one pinned block: [K 10 doubles, 10^k for k = -16..16 (CvLevMarq's lambda) | obj 3m floats | img 2m floats | samples 5*iterations ints]
     double* h_K = (double*)hs;
     float* h_obj = (float*)(hs + PNP_HDR);
     float* h_img = h_obj + (size_t)3 * m;
@@ -180,24 +147,30 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
             i++;
         }
     }
-    CKC(hipMemcpyAsync(b->d_pnp_in, hs, in_bytes, hipMemcpyHostToDevice, s));
-    const double* d_K = (const double*)b->d_pnp_in;
-    const float* d_obj = (const float*)(b->d_pnp_in + PNP_HDR);
-    const float* d_img = d_obj + (size_t)3 * m;
-    const int* d_samples = (const int*)(d_img + (size_t)2 * m);
-    double* d_rt = (double*)b->d_pnp_out;
-    int* d_info = (int*)(b->d_pnp_out + 48);
-    int* d_inl = (int*)(b->d_pnp_out + 64);
-    const float thr = (float)((double)reproj_err * (double)reproj_err);
     char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
-    CKC(launch_pnp(s, d_obj, d_img, m, d_K, d_samples, iterations, thr, confidence, b->d_models, b->d_masks, b->d_counts,
-                   d_rt, d_inl, d_info, b->d_h_stage + (ho - hs), getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr));
-    CKC(hipStreamSynchronize(s));   // the refit kernel wrote [rt | info | inliers] straight into the pinned block
+    P->K = (const double*)b->d_pnp_in;
+    P->obj = (const float*)(b->d_pnp_in + PNP_HDR);
+    P->img = P->obj + (size_t)3 * m;
+    P->samples = (const int*)(P->img + (size_t)2 * m);
+    P->models = b->d_models; P->masks = b->d_masks; P->counts = b->d_counts;
+    P->rt_out = (double*)b->d_pnp_out;
+    P->info = (int*)(b->d_pnp_out + 48);
+    P->inliers = (int*)(b->d_pnp_out + 64);
+    P->host_out = b->d_h_stage + (ho - hs);   // the refit kernel writes [rt 48 B | info 16 B | inliers] straight into the pinned block
+    P->m = m; P->n_hyp = iterations;
+    P->thr = (float)((double)reproj_err * (double)reproj_err);
+    P->confidence = confidence;
+    *in_bytes_out = in_bytes;
+}
+void pmv::pnp_finish(pmv_ctx* ctx, BackendBuffers* b, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec,
+                     int iterations, float reproj_err, double confidence, size_t in_bytes, int* out_inliers, int* out_n_inliers) {
+    const char* ho = (const char*)b->h_stage + ((in_bytes + 63) & ~(size_t)63);
     const double* h_rt = (const double*)ho;
     const int* h_info = (const int*)(ho + 48);
     const int* h_inl = (const int*)(ho + 64);
     const int n = h_info[0];
     if (ctx->log.on) {   // [kind 0, m, iterations, n_inliers | obj 3m f32 | img 2m f32 | K 9, rvec_in 3, tvec_in 3, reproj_err, confidence f64 | rvec_out 3, tvec_out 3 f64 | inliers]
+        std::lock_guard<std::mutex> lk(ctx->log.mu);
         ctx->log.blobs.emplace_back();
         std::vector<char>& bl = ctx->log.blobs.back();
         const int hdr[4] = {0, m, iterations, n};
@@ -209,6 +182,32 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     for (int i = 0; i < 3; i++) { rvec[i] = h_rt[i]; tvec[i] = h_rt[3 + i]; }
     *out_n_inliers = n;
     if (n > 0) memcpy(out_inliers, h_inl, (size_t)n * 4);
+}
+
+extern "C" {
+
+int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec,
+                   int iterations, float reproj_err, double confidence, int* out_inliers, int* out_n_inliers) {
+    int rc = pnp_check(ctx, obj_xyz, img_xy, m, K, rvec, tvec, iterations, confidence, out_inliers, out_n_inliers);
+    if (rc) return rc;
+    tl_prof = &ctx->prof;
+    CKC(hipSetDevice(ctx->device));
+    if (const char* dump = getenv("PMV_DUMP_PNP")) {   // debug: append the inputs of every call to a file
+        if (FILE* f = fopen(dump, "ab")) {
+            fwrite(&m, 4, 1, f); fwrite(obj_xyz, 12, m, f); fwrite(img_xy, 8, m, f); fwrite(K, 8, 9, f); fwrite(rvec, 8, 3, f); fwrite(tvec, 8, 3, f);
+            fclose(f);
+        }
+    }
+    BackendBuffers* b = ctx->be;
+    hipStream_t s = ctx->s_back;
+    PnPProblem P;
+    size_t in_bytes = 0;
+    pnp_prepare(b, obj_xyz, img_xy, m, K, iterations, reproj_err, confidence, &P, &in_bytes);
+    CKC(hipMemcpyAsync(b->d_pnp_in, b->h_stage, in_bytes, hipMemcpyHostToDevice, s));
+    CKC(launch_pnp(s, P.obj, P.img, m, P.K, P.samples, iterations, P.thr, confidence, P.models, P.masks, P.counts,
+                   P.rt_out, P.inliers, P.info, P.host_out, getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr));
+    CKC(hipStreamSynchronize(s));   // the refit kernel wrote [rt | info | inliers] straight into the pinned block
+    pnp_finish(ctx, b, obj_xyz, img_xy, m, K, rvec, tvec, iterations, reproj_err, confidence, in_bytes, out_inliers, out_n_inliers);
     return PMV_OK;
 }
 
@@ -274,20 +273,23 @@ int pmv_ba_residuals(pmv_ctx* ctx, const double* cams, int nc, const double* pts
     return PMV_OK;
 }
 
-int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx, const int* pt_idx,
-                 int n_obs, const double* K, double huber_delta, int max_iterations, pmv_ba_summary* summary) {
+}  // extern "C"
+
+// ---- BA: check / prepare (pinned io block, observation lists, BAArgs over b's workspaces) / finish -------------------------------
+int pmv::ba_check(pmv_ctx* ctx, const double* cams, int nc, const double* pts, int np, const double* obs_xy, const int* cam_idx, const int* pt_idx,
+                  int n_obs, const double* K, double huber_delta, int max_iterations) {
     REQ(ctx && cams && pts && obs_xy && cam_idx && pt_idx && K, PMV_ERR_INVALID, "pmv_ba_solve: null argument");
     REQ(nc >= 1 && nc <= ctx->max_ba_cams && np >= 1 && np <= ctx->max_ba_points && n_obs >= 1 && n_obs <= ctx->max_ba_obs, PMV_ERR_CAPACITY,
         "pmv_ba_solve: nc=%d np=%d n_obs=%d exceed capacity %d/%d/%d", nc, np, n_obs, ctx->max_ba_cams, ctx->max_ba_points, ctx->max_ba_obs);
     REQ(max_iterations >= 0 && max_iterations <= BA_MAX_ITERATIONS && huber_delta > 0, PMV_ERR_INVALID, "pmv_ba_solve: bad options");
-    if (max_iterations == 0) {   // ceres::Solve with max_num_iterations = 0 leaves the parameters untouched (costs are not evaluated here)
-        if (summary) { summary->initial_cost = summary->final_cost = 0.0; summary->iterations = 0; summary->successful_steps = 0; summary->termination = 0; }
-        return PMV_OK;
-    }
-    tl_prof = &ctx->prof;
-    CKC(hipSetDevice(ctx->device));
-    BackendBuffers* b = ctx->be;
-    hipStream_t s = ctx->s_back;
+    for (int i = 0; i < n_obs; i++)
+        REQ(cam_idx[i] >= 0 && cam_idx[i] < nc && pt_idx[i] >= 0 && pt_idx[i] < np, PMV_ERR_INVALID, "pmv_ba_solve: index out of range at observation %d", i);
+    const int m = 6 * nc;
+    REQ(((size_t)(m + 1) * m + (size_t)m) * 8 <= 150 * 1024, PMV_ERR_CAPACITY, "pmv_ba_solve: %d cameras exceed the LDS-resident reduced system (max 22)", nc);
+    return PMV_OK;
+}
+int pmv::ba_prepare(pmv_ctx* ctx, BackendBuffers* b, const double* cams, int nc, const double* pts, int np, const double* obs_xy, const int* cam_idx,
+                    const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations, bool multi, BAArgs* Aout, size_t* io_bytes_out) {
     // one pinned block mirrors the device block: [summary 8 | cams | pts | obs | K 10 | cam_idx | pt_idx | pstart | plist | cstart | clist]
     char* hs = (char*)b->h_stage;
     double* h_sum = (double*)hs;
@@ -300,15 +302,13 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     int* pstart = h_pi + n_obs; int* plist = pstart + (np + 1); int* cstart = plist + n_obs; int* clist = cstart + (nc + 1);
     int* odup = (int*)(((uintptr_t)(clist + n_obs) + 15) & ~(uintptr_t)15);   // 16-byte records (observation, camera, point, dup flag)
     const size_t io_bytes = (size_t)((char*)(odup + (size_t)4 * n_obs) - hs);
+    REQ(io_bytes <= b->ba_io_bytes, PMV_ERR_CAPACITY, "pmv_ba_solve: io block too small");
     memcpy(h_cams, cams, (size_t)nc * 48); memcpy(h_pts, pts, (size_t)np * 24); memcpy(h_obs, obs_xy, (size_t)n_obs * 16);
     memcpy(h_K, K, 72); memcpy(h_ci, cam_idx, (size_t)n_obs * 4); memcpy(h_pi, pt_idx, (size_t)n_obs * 4);
     // observation lists per point / per camera (counting sort, observation order preserved)
     std::fill(pstart, pstart + np + 1, 0);
     std::fill(cstart, cstart + nc + 1, 0);
-    for (int i = 0; i < n_obs; i++) {
-        REQ(cam_idx[i] >= 0 && cam_idx[i] < nc && pt_idx[i] >= 0 && pt_idx[i] < np, PMV_ERR_INVALID, "pmv_ba_solve: index out of range at observation %d", i);
-        pstart[pt_idx[i] + 1]++; cstart[cam_idx[i] + 1]++;
-    }
+    for (int i = 0; i < n_obs; i++) { pstart[pt_idx[i] + 1]++; cstart[cam_idx[i] + 1]++; }
     for (int p = 0; p < np; p++) pstart[p + 1] += pstart[p];
     for (int c = 0; c < nc; c++) cstart[c + 1] += cstart[c];
     {
@@ -325,13 +325,8 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
             odup[4 * e] = plist[e]; odup[4 * e + 1] = c; odup[4 * e + 2] = p; odup[4 * e + 3] = earlier ? 2 : (later ? 1 : 0);
         }
     }
-    // launch mode: multi (one launch per LM phase, default) | single (one persistent workgroup); PMV_BA_MODE overrides
-    static const int mode = [] { const char* e = getenv("PMV_BA_MODE"); if (getenv("PMV_BA_SINGLE")) return 0;
-                                 return (e && !strcmp(e, "single")) ? 0 : 1; }();
     const int m = 6 * nc;
     const int tiles_r = (m + 15) / 16, tiles_c = (m + 1 + 15) / 16;
-    REQ(io_bytes <= b->ba_io_bytes, PMV_ERR_CAPACITY, "pmv_ba_solve: io block too small");
-    CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
     char* dio = b->d_ba_io;
     double* d_sum = (double*)dio;
     double* d_cams = d_sum + 8;
@@ -357,22 +352,78 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     int ks = 8 / (A.tiles_r * A.tiles_c);
     if (ks < 1) ks = 1;
     if (ks > 8) ks = 8;
-    if (mode != 0) ks = 8;   // multi-kernel paths: one wavefront per (tile, K-slice) anywhere on the chip
+    if (multi) ks = 8;   // multi-kernel paths: one wavefront per (tile, K-slice) anywhere on the chip
     A.kper = round_up((A.krows + ks - 1) / ks, 16);
     A.kslices = (A.krows + A.kper - 1) / A.kper;
     REQ((size_t)A.krows * A.ldw <= b->ydwd_elems && (size_t)A.kslices * A.gp_rows * A.ldw <= b->gpart_elems, PMV_ERR_CAPACITY, "pmv_ba_solve: workspace too small");
-    REQ(((size_t)(m + 1) * m + (size_t)m) * 8 <= 150 * 1024, PMV_ERR_CAPACITY, "pmv_ba_solve: %d cameras exceed the LDS-resident reduced system (max 22)", nc);
-    // x holds two parameter vectors (current / candidate) in the multi-kernel solvers
+    if (multi) {
+        A.Wd = A.Yd + (size_t)A.krows * A.ldw;
+        A.out = (double*)b->d_h_stage;   // [summary 8 | cams | pts] of the result, straight into the pinned block
+    }
+    *Aout = A;
+    *io_bytes_out = io_bytes;
+    return PMV_OK;
+}
+void pmv::ba_finish(pmv_ctx* ctx, BackendBuffers* b, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
+                    const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations, pmv_ba_summary* summary) {
+    const double* h_out = (const double*)b->h_stage;
+    if (getenv("PMV_BA_TRACE")) {   // diagnostic: first / last camera before and after the solve
+        fprintf(stderr, "[ba-trace] nc=%d np=%d nobs=%d cost %.15g -> %.15g it %d ok %d\n", nc, np, n_obs, h_out[0], h_out[1], (int)h_out[2], (int)h_out[3]);
+        for (int c : {0, nc - 1}) {
+            fprintf(stderr, "[ba-trace]   cam %d in ", c);
+            for (int k = 0; k < 6; k++) fprintf(stderr, " %.15g", cams[6 * c + k]);
+            fprintf(stderr, "\n[ba-trace]   cam %d out", c);
+            for (int k = 0; k < 6; k++) fprintf(stderr, " %.15g", h_out[8 + 6 * c + k]);
+            fprintf(stderr, "\n");
+        }
+    }
+    if (ctx->log.on) {   // [kind 1, nc, np, n_obs, max_iterations | cams_in 6nc, pts_in 3np, obs 2n_obs, K 9, huber f64 | cam_idx, pt_idx i32 | cams_out, pts_out, summary 5 f64]
+        std::lock_guard<std::mutex> lk(ctx->log.mu);
+        ctx->log.blobs.emplace_back();
+        std::vector<char>& bl = ctx->log.blobs.back();
+        const int hdr[5] = {1, nc, np, n_obs, max_iterations};
+        pmv_call_log::put(bl, hdr, 20); pmv_call_log::put(bl, cams, (size_t)nc * 48); pmv_call_log::put(bl, pts, (size_t)np * 24);
+        pmv_call_log::put(bl, obs_xy, (size_t)n_obs * 16); pmv_call_log::put(bl, K, 72); pmv_call_log::put(bl, &huber_delta, 8);
+        pmv_call_log::put(bl, cam_idx, (size_t)n_obs * 4); pmv_call_log::put(bl, pt_idx, (size_t)n_obs * 4);
+        pmv_call_log::put(bl, h_out + 8, ((size_t)nc * 6 + (size_t)np * 3) * 8); pmv_call_log::put(bl, h_out, 40);
+    }
+    memcpy(cams, h_out + 8, (size_t)nc * 48);
+    memcpy(pts, h_out + 8 + (size_t)nc * 6, (size_t)np * 24);
+    if (summary) {
+        summary->initial_cost = h_out[0]; summary->final_cost = h_out[1]; summary->iterations = (int)h_out[2];
+        summary->successful_steps = (int)h_out[3]; summary->termination = (int)h_out[4];
+    }
+}
+
+extern "C" {
+
+int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx, const int* pt_idx,
+                 int n_obs, const double* K, double huber_delta, int max_iterations, pmv_ba_summary* summary) {
+    int rc = ba_check(ctx, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber_delta, max_iterations);
+    if (rc) return rc;
+    if (max_iterations == 0) {   // ceres::Solve with max_num_iterations = 0 leaves the parameters untouched (costs are not evaluated here)
+        if (summary) { summary->initial_cost = summary->final_cost = 0.0; summary->iterations = 0; summary->successful_steps = 0; summary->termination = 0; }
+        return PMV_OK;
+    }
+    tl_prof = &ctx->prof;
+    CKC(hipSetDevice(ctx->device));
+    BackendBuffers* b = ctx->be;
+    hipStream_t s = ctx->s_back;
+    // launch mode: multi (one launch per LM phase, default) | single (one persistent workgroup); PMV_BA_MODE overrides
+    static const int mode = [] { const char* e = getenv("PMV_BA_MODE"); if (getenv("PMV_BA_SINGLE")) return 0;
+                                 return (e && !strcmp(e, "single")) ? 0 : 1; }();
     const bool single = mode == 0;
+    BAArgs A;
+    size_t io_bytes = 0;
+    rc = ba_prepare(ctx, b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber_delta, max_iterations, !single, &A, &io_bytes);
+    if (rc) return rc;
+    char* hs = (char*)b->h_stage;
+    CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
     static const bool check = getenv("PMV_BA_CHECK") != nullptr;
     std::vector<char> saved;
     if (check) saved.assign(hs, hs + io_bytes);
     if (single) CKC(launch_ba_lm(s, A));
-    else {
-        A.Wd = A.Yd + (size_t)A.krows * A.ldw;
-        A.out = (double*)b->d_h_stage;   // [summary 8 | cams | pts] of the result, straight into the pinned block
-        CKC(launch_ba_multi(s, A, b->d_bastate, b->d_bapart));
-    }
+    else CKC(launch_ba_multi(s, A, b->d_bastate, b->d_bapart));
     const size_t out_bytes = (8 + (size_t)nc * 6 + (size_t)np * 3) * 8;
     if (single) CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));   // (multi: the finish kernel wrote into hs)
     CKC(hipStreamSynchronize(s));
@@ -404,33 +455,55 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
         }
         memcpy(hs, got.data(), out_bytes);
     }
-    if (getenv("PMV_BA_TRACE")) {   // diagnostic: first / last camera before and after the solve
-        fprintf(stderr, "[ba-trace] nc=%d np=%d nobs=%d cost %.15g -> %.15g it %d ok %d\n", nc, np, n_obs, h_out[0], h_out[1], (int)h_out[2], (int)h_out[3]);
-        for (int c : {0, nc - 1}) {
-            fprintf(stderr, "[ba-trace]   cam %d in ", c);
-            for (int k = 0; k < 6; k++) fprintf(stderr, " %.15g", cams[6 * c + k]);
-            fprintf(stderr, "\n[ba-trace]   cam %d out", c);
-            for (int k = 0; k < 6; k++) fprintf(stderr, " %.15g", h_out[8 + 6 * c + k]);
-            fprintf(stderr, "\n");
-        }
-    }
-    if (ctx->log.on) {   // [kind 1, nc, np, n_obs, max_iterations | cams_in 6nc, pts_in 3np, obs 2n_obs, K 9, huber f64 | cam_idx, pt_idx i32 | cams_out, pts_out, summary 5 f64]
-        ctx->log.blobs.emplace_back();
-        std::vector<char>& bl = ctx->log.blobs.back();
-        const int hdr[5] = {1, nc, np, n_obs, max_iterations};
-        pmv_call_log::put(bl, hdr, 20); pmv_call_log::put(bl, cams, (size_t)nc * 48); pmv_call_log::put(bl, pts, (size_t)np * 24);
-        pmv_call_log::put(bl, obs_xy, (size_t)n_obs * 16); pmv_call_log::put(bl, K, 72); pmv_call_log::put(bl, &huber_delta, 8);
-        pmv_call_log::put(bl, cam_idx, (size_t)n_obs * 4); pmv_call_log::put(bl, pt_idx, (size_t)n_obs * 4);
-        pmv_call_log::put(bl, h_out + 8, ((size_t)nc * 6 + (size_t)np * 3) * 8); pmv_call_log::put(bl, h_out, 40);
-    }
-    memcpy(cams, h_out + 8, (size_t)nc * 48);
-    memcpy(pts, h_out + 8 + (size_t)nc * 6, (size_t)np * 24);
-    if (summary) {
-        summary->initial_cost = h_out[0]; summary->final_cost = h_out[1]; summary->iterations = (int)h_out[2];
-        summary->successful_steps = (int)h_out[3]; summary->termination = (int)h_out[4];
-    }
+    ba_finish(ctx, b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber_delta, max_iterations, summary);
     return PMV_OK;
 }
+
+}  // extern "C"
+
+// ---- two-view DLT: prepare / finish -------------------------------------------------------------------------------------------
+void pmv::dlt_prepare(BackendBuffers* b, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, DltProblem* P,
+                      size_t* in_bytes_out) {
+    char* hs = (char*)b->h_stage;
+    // pinned in-block [P1x4 48 | q1 2n | q2 2n | mask n bytes], out-block [Q 16n doubles | mask 4n bytes]
+    double* h_P = (double*)hs;
+    double* h_q1 = h_P + 48;
+    double* h_q2 = h_q1 + (size_t)2 * n;
+    uint8_t* h_m = (uint8_t*)(h_q2 + (size_t)2 * n);
+    const size_t in_bytes = (48 + (size_t)4 * n) * 8 + (size_t)n;
+    memcpy(h_P, P1x4, 48 * 8); memcpy(h_q1, q1, (size_t)n * 16); memcpy(h_q2, q2, (size_t)n * 16); memcpy(h_m, mask_in, (size_t)n);
+    P->P1x4 = (const double*)b->d_tri_in;
+    P->q1 = P->P1x4 + 48;
+    P->q2 = P->q1 + (size_t)2 * n;
+    P->mask_in = (const uint8_t*)(P->q2 + (size_t)2 * n);
+    char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
+    P->Q = (double*)(b->d_h_stage + (ho - hs));   // results go straight into the pinned block (coalesced 8-byte stores)
+    P->mask = (uint8_t*)(P->Q + (size_t)16 * n);
+    P->n = n;
+    *in_bytes_out = in_bytes;
+}
+void pmv::dlt_finish(pmv_ctx* ctx, BackendBuffers* b, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,
+                     size_t in_bytes, double* out_Q, uint8_t* out_mask, int* out_good) {
+    const char* ho = (const char*)b->h_stage + ((in_bytes + 63) & ~(size_t)63);
+    memcpy(out_Q, ho, (size_t)16 * n * 8);
+    memcpy(out_mask, ho + (size_t)16 * n * 8, (size_t)4 * n);
+    for (int c = 0; c < 4; c++) {
+        int g = 0;
+        for (int i = 0; i < n; i++) g += out_mask[(size_t)c * n + i];
+        out_good[c] = g;
+    }
+    if (ctx->log.on) {   // [kind 2, n | q1 2n, q2 2n, P 48 f64 | mask_in n u8 | Q 16n f64 | mask 4n u8 | good 4 i32]
+        std::lock_guard<std::mutex> lk(ctx->log.mu);
+        ctx->log.blobs.emplace_back();
+        std::vector<char>& bl = ctx->log.blobs.back();
+        const int hdr[2] = {2, n};
+        pmv_call_log::put(bl, hdr, 8); pmv_call_log::put(bl, q1, (size_t)n * 16); pmv_call_log::put(bl, q2, (size_t)n * 16); pmv_call_log::put(bl, P1x4, 384);
+        pmv_call_log::put(bl, mask_in, (size_t)n); pmv_call_log::put(bl, out_Q, (size_t)n * 128); pmv_call_log::put(bl, out_mask, (size_t)n * 4);
+        pmv_call_log::put(bl, out_good, 16);
+    }
+}
+
+extern "C" {
 
 // the per-point part of cv::recoverPose (OpenCVFivePointTri.cpp:27): DLT triangulation + cheirality for the four candidates
 int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,
@@ -441,39 +514,13 @@ int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2,
     CKC(hipSetDevice(ctx->device));
     BackendBuffers* b = ctx->be;
     hipStream_t s = ctx->s_back;
-    char* hs = (char*)b->h_stage;
-    // pinned in-block [P1x4 48 | q1 2n | q2 2n | mask n bytes], out-block [Q 16n doubles | mask 4n bytes]
-    double* h_P = (double*)hs;
-    double* h_q1 = h_P + 48;
-    double* h_q2 = h_q1 + (size_t)2 * n;
-    uint8_t* h_m = (uint8_t*)(h_q2 + (size_t)2 * n);
-    const size_t in_bytes = (48 + (size_t)4 * n) * 8 + (size_t)n;
-    memcpy(h_P, P1x4, 48 * 8); memcpy(h_q1, q1, (size_t)n * 16); memcpy(h_q2, q2, (size_t)n * 16); memcpy(h_m, mask_in, (size_t)n);
-    CKC(hipMemcpyAsync(b->d_tri_in, hs, in_bytes, hipMemcpyHostToDevice, s));
-    const double* d_P = (const double*)b->d_tri_in;
-    const double* d_q1 = d_P + 48;
-    const double* d_q2 = d_q1 + (size_t)2 * n;
-    const uint8_t* d_m = (const uint8_t*)(d_q2 + (size_t)2 * n);
-    char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
-    double* d_Q = (double*)(b->d_h_stage + (ho - hs));   // results go straight into the pinned block (coalesced 8-byte stores)
-    uint8_t* d_mask = (uint8_t*)(d_Q + (size_t)16 * n);
-    CKC(launch_tri_dlt(s, d_P, d_q1, d_q2, d_m, n, d_Q, d_mask));
+    DltProblem P;
+    size_t in_bytes = 0;
+    dlt_prepare(b, q1, q2, n, P1x4, mask_in, &P, &in_bytes);
+    CKC(hipMemcpyAsync(b->d_tri_in, b->h_stage, in_bytes, hipMemcpyHostToDevice, s));
+    CKC(launch_tri_dlt(s, P.P1x4, P.q1, P.q2, P.mask_in, n, P.Q, P.mask));
     CKC(hipStreamSynchronize(s));
-    memcpy(out_Q, ho, (size_t)16 * n * 8);
-    memcpy(out_mask, ho + (size_t)16 * n * 8, (size_t)4 * n);
-    for (int c = 0; c < 4; c++) {
-        int g = 0;
-        for (int i = 0; i < n; i++) g += out_mask[(size_t)c * n + i];
-        out_good[c] = g;
-    }
-    if (ctx->log.on) {   // [kind 2, n | q1 2n, q2 2n, P 48 f64 | mask_in n u8 | Q 16n f64 | mask 4n u8 | good 4 i32]
-        ctx->log.blobs.emplace_back();
-        std::vector<char>& bl = ctx->log.blobs.back();
-        const int hdr[2] = {2, n};
-        pmv_call_log::put(bl, hdr, 8); pmv_call_log::put(bl, q1, (size_t)n * 16); pmv_call_log::put(bl, q2, (size_t)n * 16); pmv_call_log::put(bl, P1x4, 384);
-        pmv_call_log::put(bl, mask_in, (size_t)n); pmv_call_log::put(bl, out_Q, (size_t)n * 128); pmv_call_log::put(bl, out_mask, (size_t)n * 4);
-        pmv_call_log::put(bl, out_good, 16);
-    }
+    dlt_finish(ctx, b, q1, q2, n, P1x4, mask_in, in_bytes, out_Q, out_mask, out_good);
     return PMV_OK;
 }
 

@@ -1575,6 +1575,87 @@ hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double
     return hipGetLastError();
 }
 
+// ---- batched launch chain: blockIdx.y = problem; every block runs exactly the role code of the single-problem kernels with the
+// same block index, so each problem's result is bit-identical to its own launch_ba_multi chain ---------------------------------
+void ba_fill_prob(BAProb& P, const BAArgs& A, void* d_state, double* d_part) {
+    P.A = A;
+    P.st2[0] = d_state; P.st2[1] = (char*)d_state + 256;
+    P.chol_flags = (int*)((char*)d_state + 512);
+    P.nbo = (A.nobs + BM_T - 1) / BM_T; P.nbp = (A.np + BM_PB - 1) / BM_PB;
+    P.part_cost = d_part; P.part_gmax = P.part_cost + P.nbo; P.part4 = P.part_gmax + P.nbp; P.Ublk = P.part4 + 4 * P.nbp;
+    P.rhsblk = P.Ublk + 36 * A.nc; P.candrot = P.rhsblk + 6 * A.nc; P.tmp3 = P.candrot + 16 * A.nc;
+    P.clear_blocks = (int)std::min<size_t>(64, ((size_t)A.krows * A.ldw + 4 * BM_T - 1) / (4 * BM_T));
+    P.tiles = A.tiles_r * A.tiles_c;
+}
+__global__ __launch_bounds__(BM_T) void k_bamB_eval0(const BAProb* __restrict__ probs) {
+    const BAProb& P = probs[blockIdx.y];
+    const BAArgs A = P.A;
+    const int bx = blockIdx.x;
+    if (bx < P.nbo) { bam_eval0_role(A, (BAGState*)P.st2[1], P.chol_flags, P.part_cost, bx, P.nbo); return; }
+    const int zb = bx - P.nbo, nzb = P.clear_blocks;
+    if (zb >= nzb) return;
+    const size_t n2 = (size_t)A.krows * A.ldw;
+    double2* z = (double2*)A.Yd;
+    for (size_t i = (size_t)zb * BM_T + threadIdx.x; i < n2; i += (size_t)nzb * BM_T) z[i] = double2{0.0, 0.0};
+}
+// part: 0 = cameras only, 1 = points only (first iteration: the point role needs the camera scales), 2 = both with the decision
+__global__ __launch_bounds__(BM_T) void k_bamB_campoint(const BAProb* __restrict__ probs, int it, int part) {
+    __shared__ double swork[BM_WORK];
+    const BAProb& P = probs[blockIdx.y];
+    const BAArgs A = P.A;
+    BAGState* sin = (BAGState*)P.st2[it & 1];
+    BAGState* sc = (BAGState*)P.st2[(it + 1) & 1];
+    int* cf = P.chol_flags + it;
+    const int bx = blockIdx.x;
+    if (part == 0) { if (bx >= A.nc) return; bam_campoint_role(A, sc, sc, false, P.part4, P.nbp, cf, A.nc, P.Ublk, P.rhsblk, P.part_gmax, bx, swork); }
+    else if (part == 1) { if (bx >= P.nbp) return; bam_campoint_role(A, sc, sc, false, P.part4, P.nbp, cf, 0, P.Ublk, P.rhsblk, P.part_gmax, bx, swork); }
+    else { if (bx >= A.nc + P.nbp) return; bam_campoint_role(A, sin, sc, true, P.part4, P.nbp, cf, A.nc, P.Ublk, P.rhsblk, P.part_gmax, bx, swork); }
+}
+__global__ __launch_bounds__(64 * BG_W) void k_bamB_gemm(const BAProb* __restrict__ probs, int it) {
+    __shared__ double swork[BG_W * 4 * 64];
+    const BAProb& P = probs[blockIdx.y];
+    if ((int)blockIdx.x >= P.tiles * BG_H) return;
+    const BAArgs A = P.A;
+    bam_gemm_role(A, (const BAGState*)P.st2[(it + 1) & 1], blockIdx.x, swork);
+}
+__global__ __launch_bounds__(BM_T) void k_bamB_solve(const BAProb* __restrict__ probs, int it) {
+    const BAProb& P = probs[blockIdx.x];
+    const BAArgs A = P.A;
+    bam_solve_role(A, (BAGState*)P.st2[(it + 1) & 1], P.chol_flags + it, P.part_cost, P.nbo, P.part_gmax, P.nbp, P.Ublk, P.rhsblk, P.candrot);
+}
+__global__ __launch_bounds__(BM_T) void k_bamB_backsub(const BAProb* __restrict__ probs, int it) {
+    const BAProb& P = probs[blockIdx.y];
+    if ((int)blockIdx.x >= P.nbp) return;
+    const BAArgs A = P.A;
+    bam_backsub_role(A, (const BAGState*)P.st2[(it + 1) & 1], P.candrot, P.tmp3, P.part4, blockIdx.x);
+}
+__global__ __launch_bounds__(BM_T) void k_bamB_finish(const BAProb* __restrict__ probs, int max_it) {
+    const BAProb& P = probs[blockIdx.x];
+    const BAArgs A = P.A;
+    bam_finish_role(A, (const BAGState*)P.st2[max_it & 1], P.part4, P.nbp);
+}
+hipError_t launch_ba_multi_batch(hipStream_t s, const BAProb* d_probs, const BABatchDims& D) {
+    if (D.n_probs <= 0) return hipSuccess;
+    if (!d_probs || D.max_iterations < 1 || D.max_iterations > BA_MAX_ITERATIONS) return hipErrorInvalidValue;
+    const size_t shm = ((size_t)(D.max_m + 1) * D.max_m + (size_t)D.max_m) * sizeof(double);
+    if (shm > 150 * 1024) return hipErrorInvalidValue;
+    const unsigned np = (unsigned)D.n_probs;
+    ProfScope ps(K_BA_LM, s);
+    hipLaunchKernelGGL(k_bamB_eval0, dim3(D.max_eval_blocks, np), dim3(BM_T), 0, s, d_probs);
+    for (int it = 0; it < D.max_iterations; it++) {
+        if (it == 0) {
+            hipLaunchKernelGGL(k_bamB_campoint, dim3(D.max_nc, np), dim3(BM_T), 0, s, d_probs, it, 0);
+            hipLaunchKernelGGL(k_bamB_campoint, dim3(D.max_nbp, np), dim3(BM_T), 0, s, d_probs, it, 1);
+        } else
+            hipLaunchKernelGGL(k_bamB_campoint, dim3(D.max_nc + D.max_nbp, np), dim3(BM_T), 0, s, d_probs, it, 2);
+        hipLaunchKernelGGL(k_bamB_gemm, dim3(D.max_tiles * BG_H, np), dim3(64 * BG_W), 0, s, d_probs, it);
+        hipLaunchKernelGGL(k_bamB_solve, dim3(np), dim3(BM_T), shm, s, d_probs, it);
+        hipLaunchKernelGGL(k_bamB_backsub, dim3(D.max_nbp, np), dim3(BM_T), 0, s, d_probs, it);
+    }
+    hipLaunchKernelGGL(k_bamB_finish, dim3(np), dim3(BM_T), 0, s, d_probs, D.max_iterations);
+    return hipGetLastError();
+}
+
 hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,
                                const int* pt_idx, int nobs, const double* K, double* out_r, double* out_J) {
     if (nobs <= 0) return hipSuccess;
@@ -1593,6 +1674,8 @@ hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A) {
 // LDS opt-in (150 KB reduced camera system) per device; see frontend_prepare_device()
 hipError_t backend_prepare_device() {
     hipError_t e = hipFuncSetAttribute((const void*)k_bam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_bamB_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }

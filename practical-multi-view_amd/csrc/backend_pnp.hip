@@ -154,14 +154,14 @@ __device__ double epnp_R_and_t(const EpnpShared& sh, const double* betas, double
     return sum2 / n;
 }
 
-// grid = n_hyp, block = 64. models: n_hyp x 6 (rvec, tvec)
-__global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, const float* __restrict__ img,
-                                                const int* __restrict__ samples, const double* __restrict__ K,
-                                                double* __restrict__ models, int m, float thr, uint8_t* __restrict__ masks,
-                                                int* __restrict__ counts, unsigned long long* stamps) {
+// hypothesis h of one RANSAC problem, executed by one wavefront. models: n_hyp x 6 (rvec, tvec)
+__device__ __forceinline__ void pnp_hyp_body(const float* __restrict__ obj, const float* __restrict__ img,
+                                             const int* __restrict__ samples, const double* __restrict__ K,
+                                             double* __restrict__ models, int m, float thr, uint8_t* __restrict__ masks,
+                                             int* __restrict__ counts, unsigned long long* stamps, const int h) {
     __shared__ EpnpShared sh;
     __shared__ double sR[9], sT[3];
-    const int h = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     unsigned long long t_prev = __builtin_readcyclecounter();
 #define HSTAMP(k) do { if (stamps && h == 0 && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
     const double fu = K[0], fv = K[4], uc = K[2], vc = K[5];
@@ -502,12 +502,12 @@ __device__ inline void block_sum28(const double* acc, RefitShared& sh) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restrict__ obj, const float* __restrict__ img, int m,
-                                                           const double* __restrict__ K, const double* __restrict__ models,
-                                                           const uint8_t* __restrict__ masks, const int* __restrict__ counts,
-                                                           int n_hyp, double confidence, double* __restrict__ rt_out,
-                                                           int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out,
-                                                           unsigned long long* stamps) {
+__device__ __forceinline__ void pnp_select_refit_body(const float* __restrict__ obj, const float* __restrict__ img, int m,
+                                                      const double* __restrict__ K, const double* __restrict__ models,
+                                                      const uint8_t* __restrict__ masks, const int* __restrict__ counts,
+                                                      int n_hyp, double confidence, double* __restrict__ rt_out,
+                                                      int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out,
+                                                      unsigned long long* stamps) {
     __shared__ RefitShared sh;
     const unsigned long long t_start = __builtin_readcyclecounter();
     unsigned long long t_lm0 = 0;
@@ -702,6 +702,42 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
         int* hin = (int*)(host_out + 64);
         for (int e = tid; e < n; e += RF_T) hin[e] = inliers[e];
     }
+}
+
+// grid = n_hyp, block = 64
+__global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, const float* __restrict__ img,
+                                                const int* __restrict__ samples, const double* __restrict__ K,
+                                                double* __restrict__ models, int m, float thr, uint8_t* __restrict__ masks,
+                                                int* __restrict__ counts, unsigned long long* stamps) {
+    pnp_hyp_body(obj, img, samples, K, models, m, thr, masks, counts, stamps, blockIdx.x);
+}
+__global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restrict__ obj, const float* __restrict__ img, int m,
+                                                           const double* __restrict__ K, const double* __restrict__ models,
+                                                           const uint8_t* __restrict__ masks, const int* __restrict__ counts,
+                                                           int n_hyp, double confidence, double* __restrict__ rt_out,
+                                                           int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out,
+                                                           unsigned long long* stamps) {
+    pnp_select_refit_body(obj, img, m, K, models, masks, counts, n_hyp, confidence, rt_out, inliers, info, host_out, stamps);
+}
+// batched forms: blockIdx.y = problem (several sequences' PnP calls in one launch), same per-problem arithmetic
+__global__ __launch_bounds__(64) void k_pnp_hyp_batch(const PnPProblem* __restrict__ probs) {
+    const PnPProblem p = probs[blockIdx.y];
+    if ((int)blockIdx.x >= p.n_hyp) return;
+    pnp_hyp_body(p.obj, p.img, p.samples, p.K, p.models, p.m, p.thr, p.masks, p.counts, nullptr, blockIdx.x);
+}
+__global__ __launch_bounds__(RF_T) void k_pnp_select_refit_batch(const PnPProblem* __restrict__ probs) {
+    const PnPProblem p = probs[blockIdx.x];
+    pnp_select_refit_body(p.obj, p.img, p.m, p.K, p.models, p.masks, p.counts, p.n_hyp, p.confidence, p.rt_out, p.inliers, p.info, p.host_out, nullptr);
+}
+
+hipError_t launch_pnp_batch(hipStream_t s, const PnPProblem* d_probs, int n_probs, int max_hyp) {
+    if (n_probs <= 0) return hipSuccess;
+    if (!d_probs || max_hyp < 1) return hipErrorInvalidValue;
+    { ProfScope ps(K_PNP_HYP, s);
+    hipLaunchKernelGGL(k_pnp_hyp_batch, dim3(max_hyp, n_probs), dim3(64), 0, s, d_probs); }
+    ProfScope ps3(K_PNP_REFIT, s);
+    hipLaunchKernelGGL(k_pnp_select_refit_batch, dim3(n_probs), dim3(RF_T), 0, s, d_probs);
+    return hipGetLastError();
 }
 
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,

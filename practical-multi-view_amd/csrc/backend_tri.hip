@@ -9,10 +9,9 @@
 
 namespace pmv {
 
-__global__ __launch_bounds__(64) void k_tri_dlt(const double* __restrict__ P1x4, const double* __restrict__ q1,
-                                                const double* __restrict__ q2, const uint8_t* __restrict__ mask_in, int n,
-                                                double* __restrict__ Q, uint8_t* __restrict__ mask) {
-    const int i = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+__device__ __forceinline__ void tri_dlt_body(const double* __restrict__ P1x4, const double* __restrict__ q1,
+                                             const double* __restrict__ q2, const uint8_t* __restrict__ mask_in, int n,
+                                             double* __restrict__ Q, uint8_t* __restrict__ mask, const int i, const int c) {
     if (i >= n) return;
     double P1[12];
 #pragma unroll
@@ -49,6 +48,24 @@ __global__ __launch_bounds__(64) void k_tri_dlt(const double* __restrict__ P1x4,
     m = m && (z2 > 0) && (z2 < huge);
     m = m && (mask_in[i] != 0);
     mask[(size_t)c * n + i] = m ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_tri_dlt(const double* __restrict__ P1x4, const double* __restrict__ q1,
+                                                const double* __restrict__ q2, const uint8_t* __restrict__ mask_in, int n,
+                                                double* __restrict__ Q, uint8_t* __restrict__ mask) {
+    tri_dlt_body(P1x4, q1, q2, mask_in, n, Q, mask, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
+}
+// batched: blockIdx.z = problem
+__global__ __launch_bounds__(64) void k_tri_dlt_batch(const DltProblem* __restrict__ probs) {
+    const DltProblem p = probs[blockIdx.z];
+    tri_dlt_body(p.P1x4, p.q1, p.q2, p.mask_in, p.n, p.Q, p.mask, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
+}
+hipError_t launch_tri_dlt_batch(hipStream_t s, const DltProblem* d_probs, int n_probs, int max_n) {
+    if (n_probs <= 0 || max_n <= 0) return hipSuccess;
+    if (!d_probs) return hipErrorInvalidValue;
+    ProfScope ps(K_TRI_DLT, s);
+    hipLaunchKernelGGL(k_tri_dlt_batch, dim3((max_n + 63) / 64, 4, n_probs), dim3(64), 0, s, d_probs);
+    return hipGetLastError();
 }
 
 hipError_t launch_tri_dlt(hipStream_t s, const double* d_P1x4, const double* d_q1, const double* d_q2, const uint8_t* d_mask_in, int n,

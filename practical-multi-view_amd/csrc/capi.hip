@@ -89,7 +89,8 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     CK(hipHostGetDevicePointer((void**)&c->dm_err, c->h_err, 0));
     CK(hipMalloc(&c->d_lk_counters, 32));
     CK(hipMemset(c->d_lk_counters, 0, 32));
-    CK(hipMalloc(&c->d_cells, MAX_CELLS * 16));
+    CK(hipMalloc(&c->d_cells, MAX_CELLS * CELL_STRIDE * 4));
+    CK(hipHostMalloc(&c->h_cells, MAX_CELLS * CELL_STRIDE * 4));
     CK(hipMalloc(&c->d_eig, (size_t)MAX_CELLS * CELL_PIX * sizeof(double)));   // shared by GFTT (f32) and ShiTomasi (f64)
     CK(hipMalloc(&c->d_cellmax, MAX_CELLS * 8));
     CK(hipMalloc(&c->d_det_xy, (size_t)MAX_CELLS * MAX_PER_CELL * 8));
@@ -117,6 +118,7 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
 void pmv_ctx_destroy(pmv_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    batch_engine_destroy(c);
     ingest_destroy(c);
     if (c->s_front) hipStreamSynchronize(c->s_front);
     if (c->s_back) hipStreamSynchronize(c->s_back);
@@ -128,7 +130,7 @@ void pmv_ctx_destroy(pmv_ctx* c) {
     hipHostFree(c->h_prev_xy); hipHostFree(c->h_out_xy); hipHostFree(c->h_status); hipHostFree(c->h_err);
     hipFree(c->d_cells); hipFree(c->d_eig); hipFree(c->d_cellmax); hipFree(c->d_det_xy); hipFree(c->d_det_score);
     hipFree(c->d_det_count); hipFree(c->d_flags);
-    hipHostFree(c->h_det_xy); hipHostFree(c->h_det_score); hipHostFree(c->h_det_count);
+    hipHostFree(c->h_det_xy); hipHostFree(c->h_det_score); hipHostFree(c->h_det_count); hipHostFree(c->h_cells);
     if (c->s_front) hipStreamDestroy(c->s_front);
     if (c->s_back) hipStreamDestroy(c->s_back);
     delete c;
@@ -276,6 +278,12 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     return PMV_OK;
 }
 
+static void pack_cells(int* dst, const int* cells, int n_cells, int slot) {   // (x0, y0, w, h) -> device cell records of that frame slot
+    for (int i = 0; i < n_cells; i++) {
+        int* d = dst + (size_t)i * CELL_STRIDE;
+        d[0] = cells[4 * i]; d[1] = cells[4 * i + 1]; d[2] = cells[4 * i + 2]; d[3] = cells[4 * i + 3]; d[4] = slot; d[5] = d[6] = d[7] = 0;
+    }
+}
 static int check_cells(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell) {   // max_per_cell: already >= 1
     REQ(ctx && cells, PMV_ERR_INVALID, "detect: null argument");
     REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "detect: slot out of range");
@@ -304,9 +312,10 @@ int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int m
     tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     const PyrLayout& L = ctx->slot_layout[slot];
-    CKC(hipMemcpyAsync(ctx->d_cells, cells, (size_t)n_cells * 16, hipMemcpyHostToDevice, ctx->s_front));
+    pack_cells(ctx->h_cells, cells, n_cells, slot);
+    CKC(hipMemcpyAsync(ctx->d_cells, ctx->h_cells, (size_t)n_cells * CELL_STRIDE * 4, hipMemcpyHostToDevice, ctx->s_front));
     CKC(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->s_front));   // overflow bits are per call: one overflow must not poison later calls
-    CKC(launch_gftt(ctx->s_front, ctx->d_slots + (size_t)slot * L.slot_bytes, L, ctx->d_cells, n_cells, max_per_cell, quality,
+    CKC(launch_gftt(ctx->s_front, ctx->d_slots, L, ctx->d_cells, n_cells, max_per_cell, quality,
                     min_dist, unlimited, (float*)ctx->d_eig, (unsigned*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_count, ctx->d_flags));
     const size_t nxy = (size_t)n_cells * max_per_cell * 8;
     CKC(hipMemcpyAsync(ctx->h_det_xy, ctx->d_det_xy, nxy, hipMemcpyDeviceToHost, ctx->s_front));
@@ -333,9 +342,10 @@ int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, 
     tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     const PyrLayout& L = ctx->slot_layout[slot];
-    CKC(hipMemcpyAsync(ctx->d_cells, cells, (size_t)n_cells * 16, hipMemcpyHostToDevice, ctx->s_front));
+    pack_cells(ctx->h_cells, cells, n_cells, slot);
+    CKC(hipMemcpyAsync(ctx->d_cells, ctx->h_cells, (size_t)n_cells * CELL_STRIDE * 4, hipMemcpyHostToDevice, ctx->s_front));
     CKC(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->s_front));
-    CKC(launch_shitomasi(ctx->s_front, ctx->d_slots + (size_t)slot * L.slot_bytes, L, ctx->d_cells, n_cells, max_per_cell, quality,
+    CKC(launch_shitomasi(ctx->s_front, ctx->d_slots, L, ctx->d_cells, n_cells, max_per_cell, quality,
                          ctx->d_eig, (unsigned long long*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_score, ctx->d_det_count, ctx->d_flags));
     const size_t nxy = (size_t)n_cells * max_per_cell * 8;
     CKC(hipMemcpyAsync(ctx->h_det_xy, ctx->d_det_xy, nxy, hipMemcpyDeviceToHost, ctx->s_front));

@@ -131,19 +131,17 @@ __device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0
 // (I, Ix, Iy) samples live in registers for the whole level. A single wavefront per track is VALU-issue-bound (2.2 k cycles per
 // iteration for 16 pixels per lane); four wavefronts on the four SIMDs of a CU cut the per-iteration chain to 4 pixels per lane
 // plus one barrier. All sums are integers (order-free), so the result is bit-identical to the sequential algorithm.
-__global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS,
-                                             PyrLayout L, const float* __restrict__ prev_xy, const int* __restrict__ order, int n, LKParams P,
-                                             float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
-                                             float* __restrict__ out_err) {
+// One track through all pyramid levels; executed by one whole 256-thread block (every thread gets the same results). `stamp_on`:
+// this block feeds the diagnostic phase timers.
+struct LKResult { float x, y, err; int status, n_iter, n_lev; };
+__device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS, const PyrLayout& L,
+                                                   const float px0, const float py0, const LKParams& P, const bool stamp_on) {
     __shared__ __attribute__((aligned(16))) uint8_t sI[35 * SI_STRIDE];
     __shared__ __attribute__((aligned(16))) short2 sD[33 * SD_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t sJ[64 * SJ_STRIDE];
     __shared__ double sred[2 * LK_NW * 4];
-    const int t = order[blockIdx.x];   // block -> track (XCD-aware order built by the host; -1 = no track)
-    if (t < 0 || t >= n) return;
     const int tid = threadIdx.x;
     const int r = tid >> 3, c0 = (tid & 7) * 4;
-    const float px0 = prev_xy[2 * t], py0 = prev_xy[2 * t + 1];
     const int W = LK_WIN;
     const float half = 15.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
     int n_iter = 0, n_lev = 0;   // work counters for the roofline's measured OPS_lk
     const int ml = L.n_levels - 1;
     unsigned long long t_prev = __builtin_readcyclecounter();
-#define LSTAMP(k) do { if (P.stamps && t == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); P.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
+#define LSTAMP(k) do { if (P.stamps && stamp_on && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); P.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
     for (int level = ml; level >= 0; level--) {
         LSTAMP(0);
@@ -282,7 +280,7 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
             nx += dx; ny += dy;
             outx = nx + half; outy = ny + half;
             n_iter++;
-            if (P.stamps && t == 0 && tid == 0) P.stamps[8] += 1;
+            if (P.stamps && stamp_on && tid == 0) P.stamps[8] += 1;
             if ((double)dx * dx + (double)dy * dy <= P.eps2d) break;
             if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
@@ -326,12 +324,42 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
     }
     LSTAMP(5);
 #undef LSTAMP
-    if (tid == 0) {
-        out_xy[2 * t] = outx; out_xy[2 * t + 1] = outy;
-        out_status[t] = (uint8_t)status;
-        out_err[t] = err;
-        if (P.counters) { atomicAdd(&P.counters[0], (unsigned long long)n_iter); atomicAdd(&P.counters[1], (unsigned long long)n_lev); atomicAdd(&P.counters[2], 1ull); }
+    LKResult res;
+    res.x = outx; res.y = outy; res.err = err; res.status = status; res.n_iter = n_iter; res.n_lev = n_lev;
+    return res;
+}
+
+__device__ __forceinline__ void lk_store(const LKResult& r, int t, const LKParams& P, float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
+                                         float* __restrict__ out_err) {
+    if (threadIdx.x == 0) {
+        out_xy[2 * t] = r.x; out_xy[2 * t + 1] = r.y;
+        out_status[t] = (uint8_t)r.status;
+        out_err[t] = r.err;
+        if (P.counters) { atomicAdd(&P.counters[0], (unsigned long long)r.n_iter); atomicAdd(&P.counters[1], (unsigned long long)r.n_lev); atomicAdd(&P.counters[2], 1ull); }
     }
+}
+
+__global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS,
+                                             PyrLayout L, const float* __restrict__ prev_xy, const int* __restrict__ order, int n, LKParams P,
+                                             float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
+                                             float* __restrict__ out_err) {
+    const int t = order[blockIdx.x];   // block -> track (XCD-aware order built by the host; -1 = no track)
+    if (t < 0 || t >= n) return;
+    const LKResult r = lk_track_block(prevS, nextS, L, prev_xy[2 * t], prev_xy[2 * t + 1], P, t == 0);
+    lk_store(r, t, P, out_xy, out_status, out_err);
+}
+
+// Batched form ("same kernels with a leading batch dimension"): the blocks of several independent sequences in one
+// launch. seqs[q] = byte offsets of the prev / next frame slots of sequence q inside `slots`; blocks[b] = (q, track) with track
+// indexing the concatenated coordinate / result arrays (-1 = padding block). All sequences share the frame geometry L.
+__global__ __launch_bounds__(LK_T) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
+                                                   PyrLayout L, const float* __restrict__ prev_xy, LKParams P, float* __restrict__ out_xy,
+                                                   uint8_t* __restrict__ out_status, float* __restrict__ out_err) {
+    const int2 bt = blocks[blockIdx.x];
+    if (bt.y < 0) return;
+    const LKSeq sq = seqs[bt.x];
+    const LKResult r = lk_track_block(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, false);
+    lk_store(r, bt.y, P, out_xy, out_status, out_err);
 }
 
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
@@ -342,6 +370,15 @@ hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* nex
     if (!prev_slot || !next_slot || !d_prev_xy || !d_order || !d_out_xy || !d_status || !d_err || n_blocks < n || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     ProfScope ps(K_LK, s);
     hipLaunchKernelGGL(k_lk, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_seqs, const int2* d_blocks, int n_blocks, const PyrLayout& L,
+                           const float* d_prev_xy, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err) {
+    if (n_blocks <= 0) return hipSuccess;
+    if (!slots || !d_seqs || !d_blocks || !d_prev_xy || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
+    ProfScope ps(K_LK, s);
+    hipLaunchKernelGGL(k_lk_batch, dim3(n_blocks), dim3(LK_T), 0, s, slots, d_seqs, d_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err);
     return hipGetLastError();
 }
 
@@ -366,16 +403,16 @@ __device__ inline double f64_unkey(unsigned long long k) {
 // Phase 1: min-eigenvalue response, 32x32 outputs per 256-thread workgroup.
 // grid = (tiles_x, tiles_y, n_cells). cov at the 34x34 halo positions is evaluated at the REFLECT_101-mapped CELL
 // coordinate (box filter border = cell), from pixels of the PARENT image with REFLECT_101 on the parent (Sobel border).
-__global__ __launch_bounds__(256) void k_gftt_eig(const uint8_t* __restrict__ slot, PyrLayout L,
+__global__ __launch_bounds__(256) void k_gftt_eig(const uint8_t* __restrict__ slots, PyrLayout L,
                                                   const int* __restrict__ cells, float* __restrict__ eig,
                                                   unsigned* __restrict__ cellmax) {
     __shared__ float sC[34 * 34 * 3];
     __shared__ unsigned smax[4];
     const int cell = blockIdx.z;
-    const int cx0 = cells[4 * cell], cy0 = cells[4 * cell + 1], cw = cells[4 * cell + 2], ch = cells[4 * cell + 3];
+    const int cx0 = cells[CELL_STRIDE * cell], cy0 = cells[CELL_STRIDE * cell + 1], cw = cells[CELL_STRIDE * cell + 2], ch = cells[CELL_STRIDE * cell + 3];
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
     if (tx0 >= cw || ty0 >= ch) return;
-    const uint8_t* img = level_origin(slot, L, 0);
+    const uint8_t* img = level_origin(slots + (size_t)cells[CELL_STRIDE * cell + 4] * L.slot_bytes, L, 0);   // the cell's frame slot
     const int st = L.stride[0];
     const float k1 = (float)(1.0 / 3060.0), k2 = (float)(2.0 / 3060.0);
     for (int idx = threadIdx.x; idx < 34 * 34; idx += 256) {
@@ -439,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ ce
     unsigned long long* wbest = (unsigned long long*)(smem + GFTT_CAP * 8);  // 16
     int* scount = (int*)(smem + GFTT_CAP * 8 + 16 * 8);
     const int cell = blockIdx.x;
-    const int cw = cells[4 * cell + 2], ch = cells[4 * cell + 3];
+    const int cw = cells[CELL_STRIDE * cell + 2], ch = cells[CELL_STRIDE * cell + 3];
     const float* E = eig + (size_t)cell * CELL_PIX;
     const int tid = threadIdx.x;
     if (tid == 0) *scount = 0;
@@ -516,14 +553,14 @@ __global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ ce
     if (tid == 0) out_count[cell] = naccepted;
 }
 
-hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
+hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                        int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,
                        int* d_out_xy, int* d_out_count, int* d_flags) {
-    if (!slot || !d_cells || !d_eig || !d_cellmax || !d_out_xy || !d_out_count || !d_flags || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
+    if (!slots || !d_cells || !d_eig || !d_cellmax || !d_out_xy || !d_out_count || !d_flags || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned) * n_cells, s);
     if (e != hipSuccess) return e;
     { ProfScope ps(K_GFTT_EIG, s);
-    hipLaunchKernelGGL(k_gftt_eig, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_eig, d_cellmax); }
+    hipLaunchKernelGGL(k_gftt_eig, dim3(8, 8, n_cells), dim3(256), 0, s, slots, L, d_cells, d_eig, d_cellmax); }
     ProfScope ps2(K_GFTT_SELECT, s);
     const size_t shm = GFTT_SELECT_SHM;   // opt-in above 64 KB: frontend_prepare_device(), once per context on its device
     hipLaunchKernelGGL(k_gftt_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_eig, d_cellmax, max_per_cell,
@@ -534,16 +571,16 @@ hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, c
 // =========================================================================================================
 // ShiTomasiFeatureExtractor (in-repo arithmetic, float64)
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_st_resp(const uint8_t* __restrict__ slot, PyrLayout L,
+__global__ __launch_bounds__(256) void k_st_resp(const uint8_t* __restrict__ slots, PyrLayout L,
                                                  const int* __restrict__ cells, double* __restrict__ resp,
                                                  unsigned long long* __restrict__ cellmax) {
     __shared__ double sH[34 * 34 * 3];
     __shared__ unsigned long long smax[4];
     const int cell = blockIdx.z;
-    const int cx0 = cells[4 * cell], cy0 = cells[4 * cell + 1], cw = cells[4 * cell + 2], ch = cells[4 * cell + 3];
+    const int cx0 = cells[CELL_STRIDE * cell], cy0 = cells[CELL_STRIDE * cell + 1], cw = cells[CELL_STRIDE * cell + 2], ch = cells[CELL_STRIDE * cell + 3];
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
     if (tx0 >= cw || ty0 >= ch) return;
-    const uint8_t* img = level_origin(slot, L, 0);
+    const uint8_t* img = level_origin(slots + (size_t)cells[CELL_STRIDE * cell + 4] * L.slot_bytes, L, 0);
     const int st = L.stride[0];
     for (int idx = threadIdx.x; idx < 34 * 34; idx += 256) {
         const int hy = idx / 34, hx = idx - hy * 34;
@@ -607,7 +644,7 @@ __global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cell
     unsigned* wi = (unsigned*)(smem + ST_CAP * 12 + 16 * 8);           // 16
     int* scount = (int*)(smem + ST_CAP * 12 + 16 * 12);
     const int cell = blockIdx.x;
-    const int cw = cells[4 * cell + 2], ch = cells[4 * cell + 3];
+    const int cw = cells[CELL_STRIDE * cell + 2], ch = cells[CELL_STRIDE * cell + 3];
     const double* R = resp + (size_t)cell * CELL_PIX;
     const int tid = threadIdx.x;
     if (tid == 0) *scount = 0;
@@ -659,14 +696,14 @@ __global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cell
     if (tid == 0) out_count[cell] = nacc;
 }
 
-hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
+hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                             int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,
                             int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags) {
-    if (!slot || !d_cells || !d_resp || !d_cellmax || !d_out_xy || !d_out_score || !d_out_count || !d_flags || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
+    if (!slots || !d_cells || !d_resp || !d_cellmax || !d_out_xy || !d_out_score || !d_out_count || !d_flags || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned long long) * n_cells, s);
     if (e != hipSuccess) return e;
     { ProfScope ps(K_ST_RESP, s);
-    hipLaunchKernelGGL(k_st_resp, dim3(8, 8, n_cells), dim3(256), 0, s, slot, L, d_cells, d_resp, d_cellmax); }
+    hipLaunchKernelGGL(k_st_resp, dim3(8, 8, n_cells), dim3(256), 0, s, slots, L, d_cells, d_resp, d_cellmax); }
     ProfScope ps2(K_ST_SELECT, s);
     const size_t shm = ST_SELECT_SHM;
     hipLaunchKernelGGL(k_st_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_resp, d_cellmax, max_per_cell,

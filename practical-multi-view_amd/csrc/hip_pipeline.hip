@@ -3,11 +3,13 @@
 // every numerically heavy call crosses into the gfx950 kernels. No CPU fallback exists on this path (the triangulator,
 // which the north star does not move to the device, is the host implementation in host/vo_fivepoint.cpp).
 #include "pmv_ctx.h"
+#include "batch_engine.h"
 #include <mutex>
 #include <thread>
 #include "vo_capi_impl.h"
 #include <cstring>
 #include <stdexcept>
+#include <string>
 
 namespace {
 using namespace vo;
@@ -90,6 +92,77 @@ struct HipBA : BundleAdjustmentBase {
         ck(ctx, pmv_ba_solve(ctx, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, nullptr));
     }
 };
+// ---- the same five roles served through the batch engine (several sequences per launch, batch_engine.hip) --------------------
+struct BatchGftt : GoodFeatureExtractorBase {
+    pmv_ctx* ctx; pmv::BatchEngine* eng;
+    std::vector<int> rect, xy, cnt;
+    void gftt(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out) override {
+        out.assign(cells.size(), {});
+        if (cells.empty()) return;
+        cells_of(cells, rect);
+        const size_t cap = max > 0 ? (size_t)max : (size_t)PMV_GFTT_UNLIMITED_CAP;
+        xy.resize(cells.size() * cap * 2);
+        cnt.resize(cells.size());
+        ck(ctx, pmv::engine_detect(eng, 1, cells[0].slot, rect.data(), (int)cells.size(), max, quality, min_distance, xy.data(), nullptr, cnt.data()));
+        for (size_t c = 0; c < cells.size(); c++)
+            for (int i = 0; i < cnt[c]; i++) out[c].push_back({xy[(c * cap + i) * 2], xy[(c * cap + i) * 2 + 1]});
+    }
+};
+struct BatchShiTomasi : ShiTomasiExtractorBase {
+    pmv_ctx* ctx; pmv::BatchEngine* eng;
+    std::vector<int> rect, xy, cnt;
+    std::vector<double> sc;
+    void shitomasi(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out,
+                   std::vector<std::vector<double>>& score) override {
+        out.assign(cells.size(), {});
+        score.assign(cells.size(), {});
+        if (cells.empty() || max < 1) return;
+        cells_of(cells, rect);
+        xy.resize(cells.size() * (size_t)max * 2);
+        sc.resize(cells.size() * (size_t)max);
+        cnt.resize(cells.size());
+        ck(ctx, pmv::engine_detect(eng, 2, cells[0].slot, rect.data(), (int)cells.size(), max, quality, 0.0, xy.data(), sc.data(), cnt.data()));
+        for (size_t c = 0; c < cells.size(); c++)
+            for (int i = 0; i < cnt[c]; i++) {
+                out[c].push_back({xy[(c * max + i) * 2], xy[(c * max + i) * 2 + 1]});
+                score[c].push_back(sc[c * max + i]);
+            }
+    }
+};
+struct BatchLK : LucasKanadeFMBase {
+    pmv_ctx* ctx; pmv::BatchEngine* eng;
+    void pyrlk(const ImageView& prev, const ImageView& next, const float* prev_xy, int n, float* next_xy, uint8_t* status,
+               float* err) override {
+        ck(ctx, pmv::engine_lk(eng, prev.slot, next.slot, prev_xy, n, next_xy, status, err));
+    }
+};
+struct BatchPnP : EPnPSolverBase {
+    pmv_ctx* ctx; pmv::BatchEngine* eng; int seq;
+    bool pnp_ransac(const float* obj, const float* img, int m, const double* K, double* rvec, double* tvec,
+                    std::vector<int>& inliers) override {
+        inliers.assign(m > 0 ? m : 1, 0);
+        int n = 0;
+        const int rc = pmv::engine_pnp(eng, seq, obj, img, m, K, rvec, tvec, 100, 8.f, .99, inliers.data(), &n);
+        if (rc == PMV_ERR_DEGENERATE) { inliers.clear(); return false; }
+        ck(ctx, rc);
+        inliers.resize(n);
+        return n > 0;
+    }
+};
+struct BatchTri : vo::FivePointTri {
+    pmv_ctx* ctx; pmv::BatchEngine* eng; int seq;
+    void dlt_candidates(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
+                        uint8_t* out_mask, int* out_good) override {
+        ck(ctx, pmv::engine_dlt(eng, seq, q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good));
+    }
+};
+struct BatchBA : BundleAdjustmentBase {
+    pmv_ctx* ctx; pmv::BatchEngine* eng; int seq;
+    void ba_solve(double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx, const int* pt_idx, int n_obs,
+                  const double* K, double huber, int max_iterations) override {
+        ck(ctx, pmv::engine_ba(eng, seq, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations));
+    }
+};
 }  // namespace
 
 struct pmv_pipeline_result { vo::PipelineRun run; };
@@ -154,6 +227,83 @@ int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K
         return PMV_ERR_INVALID;
     }
     *out = res;
+    return PMV_OK;
+}
+// B independent sequences in one go. Sequence b uses frame slots first_slot[b] .. first_slot[b] + params[b].n_frames - 1
+// (staged with pmv_frames_stage; all sequences share the frame size), its own K9 (9 doubles at K9 + 9 b) and ground-truth rows.
+// Every sequence runs the reference's two host threads (front-end / back-end) with the unchanged adapters; their plugin calls are
+// merged by the context's batch engine into batched launches. out[b] receives sequence b's result, bit-identical to its own
+// pmv_pipeline_run. On error every result that exists is freed and the first error is returned.
+int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* params, const double* K9, const double* const* gt_poses12,
+                           const int* first_slot, pmv_pipeline_result** out) {
+    if (!ctx || !params || !K9 || !gt_poses12 || !first_slot || !out || B < 1) { pmv::set_err(ctx, "pmv_pipeline_run_batch: bad argument"); return PMV_ERR_INVALID; }
+    for (int b = 0; b < B; b++) {
+        const pmv_pipeline_params& P = params[b];
+        out[b] = nullptr;
+        if (P.n_frames < P.init_frames + 2 || P.init_frames < 1 || first_slot[b] < 0 || first_slot[b] + P.n_frames > ctx->n_slots) {
+            pmv::set_err(ctx, "pmv_pipeline_run_batch: sequence %d: frames [%d, %d) outside the %d slots / too short", b, first_slot[b], first_slot[b] + P.n_frames, ctx->n_slots);
+            return PMV_ERR_CAPACITY;
+        }
+        if (P.bundle_size != 0 && P.bundle_size < 3) { pmv::set_err(ctx, "pmv_pipeline_run_batch: bundle_size 1..2 divides by zero in the reference"); return PMV_ERR_INVALID; }
+        if (P.bundle_size > ctx->max_ba_cams) { pmv::set_err(ctx, "pmv_pipeline_run_batch: bundle_size exceeds max_ba_cams"); return PMV_ERR_CAPACITY; }
+        if (P.w != params[0].w || P.h != params[0].h) { pmv::set_err(ctx, "pmv_pipeline_run_batch: all sequences must share the frame size"); return PMV_ERR_INVALID; }
+    }
+    pmv::BatchEngine* eng = nullptr;
+    int rc = pmv::batch_engine_get(ctx, B, &eng);
+    if (rc != PMV_OK) return rc;
+    for (int b = 0; b < B; b++)
+        if (params[b].build_pyramids) { rc = pmv_frames_build(ctx, first_slot[b], params[b].n_frames); if (rc != PMV_OK) return rc; }
+    rc = pmv_sync(ctx);
+    if (rc != PMV_OK) return rc;
+    std::vector<int> codes(B, PMV_OK);
+    std::vector<std::string> msgs(B);
+    std::vector<std::thread> th;
+    for (int b = 0; b < B; b++)
+        th.emplace_back([&, b] {
+            const pmv_pipeline_params* P = &params[b];
+            auto* res = new pmv_pipeline_result();
+            vo::PipelineRun& run = res->run;
+            vo::PipelineParams vp;
+            vp.n_frames = P->n_frames; vp.w = P->w; vp.h = P->h;
+            vp.min_tracked_features = P->min_tracked_features; vp.tracked_features_tol = P->tracked_features_tol;
+            vp.init_frames = P->init_frames; vp.bundle_size = P->bundle_size; vp.ba_iterations = P->ba_iterations;
+            vp.extractor = P->extractor; vp.threaded = P->threaded; vp.n_threads = 1; vp.reserved = 0;
+            try {
+                vo::pipeline_setup(run, vp, nullptr, K9 + 9 * b, gt_poses12[b]);
+                for (auto& im : run.pipe.images) im.slot += first_slot[b];
+                vo::BaseFeatureExtractor* ex;
+                if (P->extractor == 1) { auto* e = new BatchShiTomasi(); e->ctx = ctx; e->eng = eng; ex = e; }
+                else { auto* e = new BatchGftt(); e->ctx = ctx; e->eng = eng; ex = e; }
+                run.owned_ex.push_back(ex);
+                auto* lk = new BatchLK(); lk->ctx = ctx; lk->eng = eng;
+                auto* pnp = new BatchPnP(); pnp->ctx = ctx; pnp->eng = eng; pnp->seq = b; pnp->tracker = &run.pipe;
+                auto* tri = new BatchTri(); tri->ctx = ctx; tri->eng = eng; tri->seq = b; tri->tracker = &run.pipe; tri->workers = 1;
+                auto* ba = new BatchBA(); ba->ctx = ctx; ba->eng = eng; ba->seq = b; ba->tracker = &run.pipe;
+                run.m = lk; run.p = pnp; run.tr = tri; run.b = ba;
+                run.pipe.extractor = ex; run.pipe.matcher = lk; run.pipe.pnpsolver = pnp; run.pipe.triangulator = tri; run.pipe.ba = ba;
+                vo::pipeline_execute(run, vp);
+                out[b] = res;
+            } catch (const HipError& e) {
+                codes[b] = e.code; msgs[b] = e.what(); delete res;
+            } catch (const std::exception& e) {
+                codes[b] = PMV_ERR_INVALID; msgs[b] = e.what(); delete res;
+            }
+        });
+    for (auto& t : th) t.join();
+    for (int b = 0; b < B; b++)
+        if (codes[b] != PMV_OK) {
+            pmv::set_err(ctx, "pmv_pipeline_run_batch: sequence %d: %s", b, msgs[b].c_str());
+            for (int k = 0; k < B; k++) { delete out[k]; out[k] = nullptr; }
+            return codes[b];
+        }
+    return PMV_OK;
+}
+// diagnostic: launches and requests the two combiners have served so far {front batches, front requests, back batches, back requests}
+int pmv_batch_stats(pmv_ctx* ctx, long long* out4) {
+    if (!ctx || !out4) return PMV_ERR_INVALID;
+    long v[4] = {0, 0, 0, 0};
+    if (ctx->engine) pmv::batch_engine_stats(ctx->engine, v);
+    for (int i = 0; i < 4; i++) out4[i] = v[i];
     return PMV_OK;
 }
 void pmv_pipeline_free(pmv_pipeline_result* r) { delete r; }

@@ -4,9 +4,11 @@
 #include "pmv_prof.h"
 #include "../../include/pmv_hip.h"
 #include <vector>
+#include <mutex>
 
 namespace pmv {
 struct Ingest;                      // streamed frame ingest (ingest.hip)
+struct BatchEngine;                 // multi-sequence combiners (batch_engine.hip)
 constexpr int MAX_CELLS = 64;       // 1920x1080 -> 8x5 = 40 cells of 255x255
 constexpr int MAX_PER_CELL = 4096;    // also the capacity of an "unlimited" (max_per_cell <= 0) goodFeaturesToTrack call
 struct BackendBuffers;              // PnP / BA device workspaces (backend.hip)
@@ -17,6 +19,7 @@ struct BackendBuffers;              // PnP / BA device workspaces (backend.hip)
 // test can replay exactly the calls a pipeline run made through another implementation. Back-end thread only.
 struct pmv_call_log {
     bool on = false;
+    std::mutex mu;                          // several back-end threads log in batch mode
     std::vector<std::vector<char>> blobs;
     static void put(std::vector<char>& b, const void* p, size_t n) { const char* c = (const char*)p; b.insert(b.end(), c, c + n); }
 };
@@ -39,6 +42,7 @@ struct pmv_ctx {
     unsigned long long* d_lk_counters = nullptr; // 4 x u64 work counters (iterations, level passes, tracks), see pmv_lk_counters
     // detectors
     int* d_cells = nullptr;
+    int* h_cells = nullptr;   // pinned staging of the device cell records
     double* d_eig = nullptr;
     void* d_cellmax = nullptr;
     int *d_det_xy = nullptr, *d_det_count = nullptr, *d_flags = nullptr;
@@ -46,6 +50,7 @@ struct pmv_ctx {
     int *h_det_xy = nullptr, *h_det_count = nullptr;
     double* h_det_score = nullptr;
     pmv::BackendBuffers* be = nullptr;
+    pmv::BatchEngine* engine = nullptr; // created by the first pmv_pipeline_run_batch
     pmv::Ingest* ingest = nullptr;      // non-null while a pmv_frames_stream_begin .. _end bracket is open
     pmv::Profiler prof;
     pmv_call_log log;
@@ -63,6 +68,7 @@ PyrLayout layout_for(pmv_ctx* ctx, int w, int h);
 // streamed ingest: make the front-end stream wait until `slot` has been copied and its pyramid built (no-op without a stream)
 int ingest_require(pmv_ctx* ctx, int slot);
 void ingest_destroy(pmv_ctx* ctx);
+void batch_engine_destroy(pmv_ctx* ctx);
 hipError_t frontend_prepare_device();   // per-device kernel attributes (LDS opt-in), called with the context's device current
 hipError_t backend_prepare_device();
 }

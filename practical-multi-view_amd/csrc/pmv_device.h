@@ -102,17 +102,23 @@ struct LKParams {
     unsigned long long* counters; // [0] += LK iterations executed (all levels), [1] += (track, level) pairs that iterated, [2] += tracks
 };
 
+struct LKSeq { unsigned long long prev_off, next_off; };   // byte offsets of a sequence's prev / next frame slot (k_lk_batch)
+hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_seqs, const int2* d_blocks, int n_blocks, const PyrLayout& L,
+                           const float* d_prev_xy, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err);
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n);
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int level_dst, int first_slot, int n);
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
                      const float* d_prev_xy, const int* d_order, int n_blocks, int n, const LKParams& P, float* d_out_xy,
                      uint8_t* d_status, float* d_err);
 
+// Detector cells on the device: CELL_STRIDE ints per cell = (x0, y0, w, h, frame slot index, 0, 0, 0) — the slot index lets one
+// launch serve cells of different frames (several sequences in one batch); `slots` is the base of the frame-slot array.
+constexpr int CELL_STRIDE = 8;
 // GFTT: eig maps (n_cells * 255*255 floats), cell max (n_cells uint32 ordered keys), outputs
-hipError_t launch_gftt(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
+hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                        int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,
                        int* d_out_xy, int* d_out_count, int* d_flags);
-hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slot, const PyrLayout& L, const int* d_cells, int n_cells,
+hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                             int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,
                             int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags);
 
