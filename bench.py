@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--tri-threads", type=int, default=8, help="host threads evaluating the triangulator's five-point RANSAC hypotheses")
     ap.add_argument("--kitti-seq", default="07", help="sequence used when KITTI_ROOT points at a KITTI odometry tree (default: synthetic data)")
     ap.add_argument("--poses-out", default="", help="write the estimated poses of the last step in KITTI format")
-    ap.add_argument("--batch", type=int, default=8, help="extra leg: B independent sequences concurrently on the GPU (0 = skip)")
+    ap.add_argument("--batch", type=int, default=64, help="extra leg: B independent sequences through batched launches on the one GPU (0 = skip)")
+    ap.add_argument("--batch-contexts", type=int, default=0, help="diagnostic: also run the round-1 form (B contexts x 2 host threads x 2 streams)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the pcie_inclusive (streamed from host memory) leg")
     args = ap.parse_args()
 
@@ -104,9 +105,19 @@ def main():
             dist.init_process_group(backend=backend)
         local_rank = dev_index
 
-    # The batched leg drives 2 HIP streams per sequence; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4),
-    # and streams that share a queue serialise. Measured with 8 sequences: 4 queues 5100 frames/s, 8 -> 6400, 16 -> 7200.
+    # The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise; the batch
+    # engine uses 5 streams + the context's 3.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # A one-GPU box share is 16 CPUs, enforced as a CFS quota over all 256 hardware threads: unpinned, ~70 runnable threads spread
+    # over the machine, burn the quota in bursts and run cache-cold (measured: 672 us of CPU per frame in the batched leg, 457 us
+    # pinned). Every rank therefore pins itself to its own 16 CPUs — the CPU baseline runs under the same mask.
+    if not os.environ.get("PMV_BENCH_NO_PIN"):
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+            if len(allowed) >= 16 * (local_rank + 1) and len(allowed) > 16:
+                os.sched_setaffinity(0, allowed[16 * local_rank: 16 * (local_rank + 1)])
+        except (AttributeError, OSError):
+            pass
     pmv = importlib.import_module("practical-multi-view_amd")
     sh = importlib.import_module("practical-multi-view_amd.sharding")
     if not os.path.exists(pmv.lib_path()):
@@ -390,16 +401,65 @@ def main():
                    poses_agree_1e6_until_frame=int(bad[0]) if len(bad) else int(len(o.poses)),
                    stage_seconds={k_: round(float(o.stats[k_]), 3) for k_ in ("t_lk", "t_detect", "t_pnp", "t_tri", "t_ba")})
 
-    # ---- batched leg: B independent sequences on ONE GPU, one context + front/back host threads each ----------
+    # ---- batched leg: B independent sequences on ONE GPU through batched launches (batch_engine.hip) ---------------
     batched = None
     if args.batch > 1 and world == 1 and args.config == 1:
-        import threading
         B = args.batch
+        frames, gt = data[0]
+        n = frames.shape[0]
+        bc = pmv.Context(w, h, **dict(ctx_kw, n_slots=B * n, max_tracks=1024, max_ba_cams=8, max_ba_points=4096, max_ba_obs=32768))
+        for b in range(B):
+            bc.frames_stage(b * n, frames)     # the same frames in every slot range: a throughput leg, every run is a full independent pass
+        seqs = [(b * n, n, gt) for b in range(B)]
+        bkw = dict(min_tracked=cfg["min_tracked"], tol=cfg["tol"], init_frames=INIT_FRAMES, bundle_size=cfg["bundle_size"], ba_iterations=BA_ITERATIONS,
+                   want_features=False, defer_free=True, threaded=0)
+        warm = bc.pipeline_run_batch(seqs, w, h, K, **bkw)
+        bc.sync()
+        s0 = bc.batch_stats()
+        bc.prof_enable(True)
+        t1 = time.perf_counter()
+        c1 = time.process_time()
+        results = bc.pipeline_run_batch(seqs, w, h, K, **bkw)
+        bc.sync()
+        dtb = time.perf_counter() - t1
+        cpu_b = time.process_time() - c1
+        bc.prof_enable(False)
+        bprof = bc.prof_read()
+        s1 = bc.batch_stats()
+        same = all(np.array_equal(r_.poses, res.poses) for r_ in results)
+        fr_b = sum(n - int(r_.stats["init_offset"]) for r_ in results)
+        rounds = {}
+        for role in s1:
+            d_ = {k_: s1[role][k_] - s0[role][k_] for k_ in s1[role]}
+            if d_["launches"]:
+                rounds[role] = dict(launch_rounds=d_["launches"], requests_per_round=round(d_["requests"] / d_["launches"], 2),
+                                    avg_round_us=round(d_["work_s"] / d_["launches"] * 1e6, 1), gpu_wait_s=round(d_["sync_s"], 3))
+        bk = {k_: dict(launches=v[0], avg_us=round(v[1] / v[0] * 1e3, 2)) for k_, v in bprof.items()}
+        # roofline of the batched k_lk launch: HBM view (every sequence's two pyramids once per round) and measured VALU-int work
+        lk_round = rounds.get("lk", {})
+        b_roof = None
+        if "k_lk" in bprof and lk_round:
+            t_l = bprof["k_lk"][1] / bprof["k_lk"][0] * 1e-3
+            alg = lk_round["requests_per_round"] * (2.0 * pyr_px + 13.0 * lk_n)
+            b_roof = dict(kernel="k_lk_batch", bound="hbm", achieved=round(alg / t_l / 1e9, 3), peak=PEAK_HBM_GBS, unit="GB/s", frac=alg / t_l / 1e9 / PEAK_HBM_GBS,
+                          avg_launch_us=round(t_l * 1e6, 1), algorithmic_per_launch=round(alg, 1), traffic=None,
+                          note=f"{lk_round['requests_per_round']} sequences' tracks per launch on average")
+        batched = dict(sequences=B, value=round(fr_b / dtb, 3), unit="frames/s", seconds=round(dtb, 3), identical_to_single_run=bool(same),
+                       host_threads=B + 5, host_cpu_us_per_frame=round(cpu_b / fr_b * 1e6, 1), host_cores_busy=round(cpu_b / dtb, 2),
+                       combiners=rounds, kernels=bk, roofline=b_roof,
+                       how="pmv_pipeline_run_batch: one host thread per sequence (unchanged adapters), five combiner threads merge the plugin calls "
+                           "into batched launches (k_lk_batch, detectors, k_pnp_*_batch, k_bamB_* chain, k_tri_dlt_batch), one HIP stream per class")
+        for r_ in warm + results:
+            r_.free()
+        bc.close()
+    if args.batch_contexts > 1 and world == 1 and args.config == 1:
+        import threading
+        B = args.batch_contexts
         frames, gt = data[0]
         n = frames.shape[0]
         bctx = [ctx] + [pmv.Context(w, h, **dict(ctx_kw, n_slots=n)) for _ in range(B - 1)]
         for c in bctx[1:]:
-            c.frames_stage(0, frames)      # the same frames in every context: a throughput leg, every run is a full independent pass
+            c.frames_stage(0, frames)
         results = [None] * B
 
         def worker(i):
@@ -414,7 +474,7 @@ def main():
         run_all()                          # warm-up
         for c in bctx:
             c.sync()
-        warm_results = list(results)       # kept alive: their (host-container) teardown happens after the timed pass
+        warm_results = list(results)
         t1 = time.perf_counter()
         run_all()
         for c in bctx:
@@ -422,9 +482,10 @@ def main():
         dtb = time.perf_counter() - t1
         for r_ in warm_results:
             r_.free()
-        same = all(np.array_equal(results[i].poses, res.poses) for i in range(B))
-        batched = dict(sequences=B, value=round(B * (n - int(st["init_offset"])) / dtb, 3), unit="frames/s", seconds=round(dtb, 3),
-                       host_threads=2 * B, identical_to_single_run=bool(same), how="B contexts x (front-end + back-end host threads), 2 HIP streams each")
+        if batched is None:
+            batched = {}
+        batched["contexts_form"] = dict(sequences=B, value=round(B * (n - int(st["init_offset"])) / dtb, 3), unit="frames/s", seconds=round(dtb, 3),
+                                        how="round-1 form: B contexts x (front-end + back-end host threads), 2 HIP streams each")
         ctx.pipeline_drain()
         for c in bctx[1:]:
             c.close()
@@ -470,6 +531,8 @@ def main():
     }
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
+        if batched and "value" in batched:
+            out["batched_speedup_vs_cpu_baseline"] = round(batched["value"] / cpu["value"], 2)
     if args.config != 1 or args.frames:
         out["note"] = "not the metric configuration: this line is a diagnostic for the named workload"
     kitti_mod = importlib.import_module("practical-multi-view_amd.kitti")

@@ -187,11 +187,13 @@ int pmv_pipeline_run_streamed(pmv_ctx* ctx, const pmv_pipeline_params* params, c
 /* B independent sequences through batched launches (SURVEY.md §8e "same kernels with a leading batch dimension"): sequence b =
  * frame slots first_slot[b] .. + params[b].n_frames - 1 (pmv_frames_stage; one frame size for all), intrinsics K9 + 9 b, ground
  * truth gt_poses12[b]. Each sequence keeps the reference's front-end / back-end host threads; their plugin calls are merged into
- * one k_lk_batch / detector / k_pnp_*_batch / k_bamB_* / k_tri_dlt_batch launch per kernel class by two combiner threads, which
- * are the only ones that talk to the HIP runtime. out[b] is bit-identical to the same sequence's own pmv_pipeline_run. */
+ * one k_lk_batch / detector / k_pnp_*_batch / k_bamB_* / k_tri_dlt_batch launch per kernel class by that class's combiner
+ * thread (one HIP stream each); the combiners are the only threads that talk to the HIP runtime. out[b] is bit-identical to the same sequence's own pmv_pipeline_run. */
 int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* params, const double* K9, const double* const* gt_poses12,
                            const int* first_slot, pmv_pipeline_result** out);
-int pmv_batch_stats(pmv_ctx* ctx, long long* out4);   /* {front launches, front requests, back launches, back requests} so far */
+/* diagnostic, per combiner in the order LK, detectors, PnP, BA, DLT: counts10 = {launch rounds, requests served} x 5; times15 (may
+ * be NULL) = seconds spent {CPU time of the combiner thread, wall time processing batches, of that waiting for the GPU} x 5 */
+int pmv_batch_stats(pmv_ctx* ctx, long long* counts10, double* times15);
 void pmv_pipeline_free(pmv_pipeline_result* r);
 /* Same, but the (host-container) teardown runs on a background thread; pmv_pipeline_drain() joins all of them. */
 void pmv_pipeline_release(pmv_pipeline_result* r);

@@ -448,7 +448,7 @@ class Context:
         return r
 
     def pipeline_run_batch(self, seqs, w, h, K, min_tracked=400, tol=150, init_frames=5, bundle_size=5, ba_iterations=5, extractor=0,
-                           build_pyramids=1, want_features=True, defer_free=False):
+                           build_pyramids=1, want_features=True, defer_free=False, threaded=1):
         """B independent sequences through batched launches (pmv_pipeline_run_batch). seqs: list of (first_slot, n_frames, gt_poses);
         the frames must be staged in slots first_slot..first_slot+n_frames-1. K: 9 values shared by all, or (B, 9). Returns one
         PipelineResult per sequence (bit-identical to pipeline_run on the same sequence)."""
@@ -459,7 +459,7 @@ class Context:
         first = (C.c_int * B)()
         Kd = np.ascontiguousarray(np.broadcast_to(np.asarray(K, np.float64).reshape(-1, 9), (B, 9)))
         for b, (fs, n, gt) in enumerate(seqs):
-            params[b] = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, 1, 1, build_pyramids)
+            params[b] = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded, 1, build_pyramids)
             g = np.ascontiguousarray(gt, np.float64).reshape(n, 12)
             gts.append(g)
             gt_ptrs[b] = _p(g, _f64p)
@@ -479,10 +479,14 @@ class Context:
         return res
 
     def batch_stats(self):
-        """{front launches, front requests, back launches, back requests} of the batch engine's two combiners"""
-        out = (C.c_longlong * 4)()
-        self.lib.pmv_batch_stats(self.h, out)
-        return dict(front_launches=int(out[0]), front_requests=int(out[1]), back_launches=int(out[2]), back_requests=int(out[3]))
+        """per combiner of the batch engine (lk, det, pnp, ba, dlt): launch rounds, requests served, CPU seconds of the thread, wall seconds processing batches / of that waiting for the GPU"""
+        cnt = (C.c_longlong * 10)()
+        t = (C.c_double * 15)()
+        self.lib.pmv_batch_stats(self.h, cnt, t)
+        out = {}
+        for r, name in enumerate(("lk", "det", "pnp", "ba", "dlt")):
+            out[name] = dict(launches=int(cnt[2 * r]), requests=int(cnt[2 * r + 1]), cpu_s=t[3 * r], work_s=t[3 * r + 1], sync_s=t[3 * r + 2])
+        return out
 
     def pipeline_drain(self):
         self.lib.pmv_pipeline_drain()

@@ -6,7 +6,9 @@ namespace pmv {
 struct BatchEngine;
 int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out);   // creates (or grows) the context's engine for B concurrent sequences
 void batch_engine_destroy(pmv_ctx* ctx);
-void batch_engine_stats(BatchEngine* E, long* out4);            // front batches, front requests, back batches, back requests
+// per combiner (LK, detectors, PnP, BA, DLT): counts10 = {launch rounds, requests} x 5; times15 (may be null) = seconds spent
+// {CPU time of the combiner thread, wall time processing batches, of that waiting for the GPU} x 5
+void batch_engine_stats(BatchEngine* E, long long* counts10, double* times15);
 // same contracts as pmv_lk_track / pmv_detect_* / pmv_pnp_ransac / pmv_ba_solve / pmv_triangulate_candidates; `seq` selects the
 // sequence's back-end workspace set. Blocking; safe to call from many threads at once (one outstanding call per seq and stream role).
 int engine_lk(BatchEngine* E, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy, uint8_t* status, float* err);

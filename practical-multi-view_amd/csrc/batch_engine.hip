@@ -3,14 +3,15 @@
 // A single sequence can never fill 256 CUs: frame k+1's tracks depend on frame k's result (~300 workgroups in flight) and the
 // back-end is a serial chain of small solves. Sequences, however, are independent (the path shards by sequence). Here every
 // sequence keeps the reference's own host structure — a front-end and a back-end thread running the unchanged adapters of
-// host/vo_pipeline.cpp — but its plugin calls do not launch anything themselves: they hand a request to one of two COMBINER
-// threads (front-end stream: LK + detectors; back-end stream: PnP + BA + two-view DLT) and sleep. A combiner takes whatever
-// requests have accumulated while the previous launch was running, issues ONE batched launch per kernel class for all of them
-// (k_lk_batch, k_gftt_* over the cells of several frames, k_pnp_*_batch, the k_bamB_* chain with the problem index in
-// blockIdx.y, k_tri_dlt_batch), synchronises once and wakes the callers. Only the two combiner threads talk to the HIP runtime,
-// so there is no runtime-lock contention and no per-sequence stream; the batch size adapts to the load by itself. Every
-// block of a batched launch executes exactly the code and the block index of the single-sequence launch, so each sequence's
-// results are bit-identical to its own single run (tests/test_batch_gpu.py).
+// host/vo_pipeline.cpp — but its plugin calls do not launch anything themselves: they hand a request to the COMBINER thread of
+// their kernel class (LK, detectors, PnP, BA, two-view DLT; one HIP stream each, so the classes overlap on the GPU) and sleep. A
+// combiner takes whatever requests have accumulated while its previous launch was running, issues ONE batched launch for all of
+// them (k_lk_batch, k_gftt_* / k_st_* over the cells of several frames, k_pnp_*_batch, the k_bamB_* chain with the problem index
+// in blockIdx.y, k_tri_dlt_batch), synchronises once and wakes exactly the callers it served. Only the five combiner threads talk
+// to the HIP runtime: no runtime-lock contention, no per-sequence stream; the batch size adapts to the load by itself. Inputs that
+// the callers prepared in their pinned blocks are pulled into HBM by one gather kernel per batch (k_stage_in) instead of one DMA
+// per request. Every block of a batched launch executes exactly the code and the block index of the single-sequence launch, so
+// each sequence's results are bit-identical to its own single run (tests/test_batch_gpu.py).
 #include "pmv_ctx.h"
 #include "backend.h"
 #include "batch_engine.h"
@@ -20,6 +21,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <thread>
+#include <time.h>
 
 namespace pmv {
 
@@ -29,6 +31,7 @@ struct Req {
     int kind = 0;          // 0 LK, 1 GFTT, 2 ShiTomasi | 10 PnP, 11 BA, 12 DLT
     int rc = PMV_OK;
     bool done = false;
+    std::condition_variable cv;   // only the owner of a finished request is woken (no thundering herd of all waiting sequences)
     char err[200] = "";
     virtual ~Req() {}
 };
@@ -61,14 +64,30 @@ struct Growable {   // device (or pinned host) buffer that only grows
     void release() { if (p) { (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; cap = 0; } }
 };
 
+enum Role { R_LK = 0, R_DET, R_PNP, R_BA, R_DLT, R_COUNT };
 struct Combiner {
     std::mutex mu;
-    std::condition_variable cv_new, cv_done;
+    std::condition_variable cv_new;
     std::vector<Req*> pending;
     bool stop = false;
     std::thread th;
+    hipStream_t s = nullptr;           // this class's own stream
+    hipEvent_t ev = nullptr;           // blocking-sync event for the interrupt-driven wait
+    Growable h_desc{nullptr, 0, true}, d_desc;   // per-batch descriptors (+ stage-in jobs), pinned mirror and device copy
     long batches = 0, requests = 0;
+    double t_idle = 0, t_work = 0, t_sync = 0;   // seconds: waiting for requests / processing a batch / inside hipStreamSynchronize
+    double t_cpu = 0;                            // CPU seconds of the combiner thread itself
 };
+
+// one input block to pull from mapped pinned host memory into HBM (16-byte granules; both buffers have >= 16 B of slack)
+struct StageJob { const char* src; char* dst; unsigned bytes, pad; };
+__global__ __launch_bounds__(256) void k_stage_in(const StageJob* __restrict__ jobs) {
+    const StageJob j = jobs[blockIdx.y];
+    const unsigned n16 = (j.bytes + 15u) >> 4;
+    const uint4* __restrict__ src = (const uint4*)j.src;
+    uint4* __restrict__ dst = (uint4*)j.dst;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
 
 }  // namespace
 
@@ -76,16 +95,15 @@ struct BatchEngine {
     pmv_ctx* ctx = nullptr;
     int B = 0;
     int linger_us = 0;
+    int wait_mode = 2;   // 0 spin (hipStreamSynchronize), 1 query + yield, 2 blocking event
     std::vector<BackendBuffers*> slots;   // one back-end workspace set per concurrent sequence
-    Combiner front, back;
+    Combiner comb[R_COUNT];
     // front staging
     Growable h_front{nullptr, 0, true}, d_front, h_cells{nullptr, 0, true}, d_cells, d_eig, d_cellmax, d_det_xy, d_det_score, d_det_count, h_det{nullptr, 0, true};
     float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr;    // mapped pinned LK results
     float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr;
     size_t cap_tracks = 0;
     int* d_flags = nullptr;
-    // back descriptors
-    Growable h_desc{nullptr, 0, true}, d_desc;
 };
 
 namespace {
@@ -95,13 +113,32 @@ void fail_all(std::vector<Req*>& batch, int code, const char* what, hipError_t e
 }
 #define EK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail_all(batch, PMV_ERR_HIP, #x, e_); return; } } while (0)
 
-// ---- front-end stream ---------------------------------------------------------------------------------------------------------
-void process_front(BatchEngine* E, std::vector<Req*>& batch) {
+// Waiting for a batch: hipStreamSynchronize spins on a host core; with five combiners and 2 B sequence threads on a 16-core share
+// the cores are better spent on the sequences' host work, so the default is an interrupt-driven wait on a blocking event
+// (PMV_BATCH_WAIT=spin | yield | block).
+hipError_t wait_stream(BatchEngine* E, Combiner& C);
+#define SYNC_TIMED(C) do { const auto t0_ = std::chrono::steady_clock::now(); EK(wait_stream(E, (C))); (C).t_sync += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); } while (0)
+
+hipError_t wait_stream(BatchEngine* E, Combiner& C) {
+    if (E->wait_mode == 0) return hipStreamSynchronize(C.s);
+    if (E->wait_mode == 1) {
+        for (;;) {
+            const hipError_t e = hipStreamQuery(C.s);
+            if (e != hipErrorNotReady) return e;
+            std::this_thread::yield();
+        }
+    }
+    hipError_t e = hipEventRecord(C.ev, C.s);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(C.ev);
+}
+
+// ---- LK -------------------------------------------------------------------------------------------------------------------------
+void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     pmv_ctx* ctx = E->ctx;
-    hipStream_t s = ctx->s_front;
+    hipStream_t s = C.s;
     std::vector<LKReq*> lk;
-    std::vector<DetReq*> det;
-    for (Req* r : batch) { if (r->kind == 0) lk.push_back((LKReq*)r); else det.push_back((DetReq*)r); }
+    for (Req* r : batch) lk.push_back((LKReq*)r);
     // ---- LK: one launch for the tracks of every requesting sequence
     int total_tracks = 0, total_blocks = 0;
     PyrLayout L{};
@@ -142,6 +179,22 @@ void process_front(BatchEngine* E, std::vector<Req*>& batch) {
         EK(launch_lk_batch(s, ctx->d_slots, (const LKSeq*)db, (const int2*)(db + off_blocks), total_blocks, L, (const float*)(db + off_xy), P,
                            E->dm_out_xy, E->dm_status, E->dm_err));
     }
+    SYNC_TIMED(C);
+    for (LKReq* r : lk) {
+        if (r->rc != PMV_OK) continue;
+        memcpy(r->out_xy, E->h_out_xy + (size_t)2 * r->base, (size_t)r->n * 8);
+        memcpy(r->status, E->h_status + r->base, (size_t)r->n);
+        memcpy(r->err_out, E->h_err + r->base, (size_t)r->n * 4);
+    }
+}
+
+// ---- detectors --------------------------------------------------------------------------------------------------------------------
+void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
+    pmv_ctx* ctx = E->ctx;
+    hipStream_t s = C.s;
+    std::vector<DetReq*> det;
+    for (Req* r : batch) det.push_back((DetReq*)r);
+    PyrLayout L = ctx->slot_layout[det[0]->slot];
     // ---- detectors: requests with the same parameters share a launch (cells of several frames)
     struct Group { int kind, max_per_cell, unlimited; double quality, min_dist; std::vector<DetReq*> reqs; int n_cells = 0; size_t out_off = 0; };
     std::vector<Group> groups;
@@ -154,8 +207,7 @@ void process_front(BatchEngine* E, std::vector<Req*>& batch) {
         g->n_cells += r->n_cells;
         g->reqs.push_back(r);
     }
-    if (!groups.empty()) {
-        if (!have_L) L = ctx->slot_layout[det[0]->slot];
+    {
         size_t tot_cells = 0, tot_out = 0;
         for (Group& g : groups) { g.out_off = tot_out; tot_cells += g.n_cells; tot_out += (size_t)g.n_cells * g.max_per_cell; }
         EK(E->h_cells.ensure(tot_cells * CELL_STRIDE * 4)); EK(E->d_cells.ensure(tot_cells * CELL_STRIDE * 4));
@@ -192,14 +244,8 @@ void process_front(BatchEngine* E, std::vector<Req*>& batch) {
         EK(hipMemcpyAsync(hd + tot_out * 16, E->d_det_count.p, tot_cells * 4, hipMemcpyDeviceToHost, s));
         EK(hipMemcpyAsync(hd + tot_out * 16 + tot_cells * 4, E->d_flags, 4, hipMemcpyDeviceToHost, s));
     }
-    EK(hipStreamSynchronize(s));
-    for (LKReq* r : lk) {
-        if (r->rc != PMV_OK) continue;
-        memcpy(r->out_xy, E->h_out_xy + (size_t)2 * r->base, (size_t)r->n * 8);
-        memcpy(r->status, E->h_status + r->base, (size_t)r->n);
-        memcpy(r->err_out, E->h_err + r->base, (size_t)r->n * 4);
-    }
-    if (!groups.empty()) {
+    SYNC_TIMED(C);
+    {
         size_t tot_cells = 0, tot_out = 0;
         for (Group& g : groups) { tot_cells += g.n_cells; tot_out += (size_t)g.n_cells * g.max_per_cell; }
         const char* hd = (const char*)E->h_det.p;
@@ -221,68 +267,98 @@ void process_front(BatchEngine* E, std::vector<Req*>& batch) {
     }
 }
 
-// ---- back-end stream ----------------------------------------------------------------------------------------------------------
-void process_back(BatchEngine* E, std::vector<Req*>& batch) {
-    pmv_ctx* ctx = E->ctx;
-    hipStream_t s = ctx->s_back;
-    std::vector<PnPReq*> pnp; std::vector<BAReq*> ba; std::vector<DltReq*> dlt;
-    for (Req* r : batch) { if (r->kind == 10) pnp.push_back((PnPReq*)r); else if (r->kind == 11) ba.push_back((BAReq*)r); else dlt.push_back((DltReq*)r); }
-    const size_t off_ba = (sizeof(PnPProblem) * pnp.size() + 255) & ~(size_t)255;
-    const size_t off_dlt = (off_ba + sizeof(BAProb) * ba.size() + 255) & ~(size_t)255;
-    const size_t desc_bytes = off_dlt + sizeof(DltProblem) * dlt.size();
-    EK(E->h_desc.ensure(desc_bytes + 256)); EK(E->d_desc.ensure(desc_bytes + 256));
-    char* hd = (char*)E->h_desc.p;
-    char* dd = (char*)E->d_desc.p;
-    int max_hyp = 0;
-    for (size_t i = 0; i < pnp.size(); i++) {
-        PnPReq* r = pnp[i];
-        EK(hipMemcpyAsync(r->b->d_pnp_in, r->b->h_stage, r->in_bytes, hipMemcpyHostToDevice, s));
-        ((PnPProblem*)hd)[i] = r->P;
-        max_hyp = std::max(max_hyp, r->P.n_hyp);
-    }
-    // BA: one chain per distinct iteration cap (in practice one)
-    std::vector<int> ba_iters;
-    for (BAReq* r : ba) if (std::find(ba_iters.begin(), ba_iters.end(), r->max_iterations) == ba_iters.end()) ba_iters.push_back(r->max_iterations);
-    std::vector<BAReq*> ba_sorted;
-    for (int it : ba_iters) for (BAReq* r : ba) if (r->max_iterations == it) ba_sorted.push_back(r);
-    for (size_t i = 0; i < ba_sorted.size(); i++) {
-        BAReq* r = ba_sorted[i];
-        EK(hipMemcpyAsync(r->b->d_ba_io, r->b->h_stage, r->io_bytes, hipMemcpyHostToDevice, s));
-        ba_fill_prob(((BAProb*)(hd + off_ba))[i], r->A, r->b->d_bastate, r->b->d_bapart);
-    }
-    int max_n = 0;
-    for (size_t i = 0; i < dlt.size(); i++) {
-        DltReq* r = dlt[i];
-        EK(hipMemcpyAsync(r->b->d_tri_in, r->b->h_stage, r->in_bytes, hipMemcpyHostToDevice, s));
-        ((DltProblem*)(hd + off_dlt))[i] = r->P;
-        max_n = std::max(max_n, r->P.n);
-    }
-    EK(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, s));
-    if (!pnp.empty()) EK(launch_pnp_batch(s, (const PnPProblem*)dd, (int)pnp.size(), max_hyp));
-    size_t i0 = 0;
-    for (int it : ba_iters) {
-        BABatchDims D{0, 0, 0, 0, 0, 0, it};
-        size_t i1 = i0;
-        while (i1 < ba_sorted.size() && ba_sorted[i1]->max_iterations == it) {
-            const BAProb& P = ((const BAProb*)(hd + off_ba))[i1];
-            D.max_eval_blocks = std::max(D.max_eval_blocks, P.nbo + P.clear_blocks);
-            D.max_nc = std::max(D.max_nc, P.A.nc); D.max_nbp = std::max(D.max_nbp, P.nbp); D.max_tiles = std::max(D.max_tiles, P.tiles);
-            D.max_m = std::max(D.max_m, 6 * P.A.nc);
-            i1++;
-        }
-        D.n_probs = (int)(i1 - i0);
-        EK(launch_ba_multi_batch(s, (const BAProb*)(dd + off_ba) + i0, D));
-        i0 = i1;
-    }
-    if (!dlt.empty()) EK(launch_tri_dlt_batch(s, (const DltProblem*)(dd + off_dlt), (int)dlt.size(), max_n));
-    EK(hipStreamSynchronize(s));   // every kernel wrote its results straight into the requests' pinned blocks
+// ---- back-end classes: the callers prepared their inputs in their slot's pinned block; one gather kernel pulls them into HBM ----
+// descriptor block of a batch: [problem records | stage-in jobs]
+template <class Prob> struct DescBlock { Prob* hprob; StageJob* hjobs; const Prob* dprob; const StageJob* djobs; size_t bytes; };
+template <class Prob>
+hipError_t desc_block(Combiner& C, size_t n, DescBlock<Prob>& D) {
+    const size_t off_jobs = (sizeof(Prob) * n + 255) & ~(size_t)255;
+    D.bytes = off_jobs + sizeof(StageJob) * n;
+    hipError_t e = C.h_desc.ensure(D.bytes + 256);
+    if (e != hipSuccess) return e;
+    e = C.d_desc.ensure(D.bytes + 256);
+    if (e != hipSuccess) return e;
+    D.hprob = (Prob*)C.h_desc.p; D.hjobs = (StageJob*)((char*)C.h_desc.p + off_jobs);
+    D.dprob = (const Prob*)C.d_desc.p; D.djobs = (const StageJob*)((const char*)C.d_desc.p + off_jobs);
+    return hipSuccess;
+}
+template <class Prob>
+hipError_t stage_in(Combiner& C, const DescBlock<Prob>& D, size_t n, int blocks_per_job) {
+    hipError_t e = hipMemcpyAsync(C.d_desc.p, C.h_desc.p, D.bytes, hipMemcpyHostToDevice, C.s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stage_in, dim3(blocks_per_job, (unsigned)n), dim3(256), 0, C.s, D.djobs);
+    return hipGetLastError();
 }
 
-void combiner_loop(BatchEngine* E, Combiner* C, bool is_front) {
+void process_pnp(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
+    DescBlock<PnPProblem> D;
+    EK(desc_block(C, batch.size(), D));
+    int max_hyp = 0;
+    for (size_t i = 0; i < batch.size(); i++) {
+        PnPReq* r = (PnPReq*)batch[i];
+        D.hprob[i] = r->P;
+        D.hjobs[i] = StageJob{(const char*)r->b->d_h_stage, r->b->d_pnp_in, (unsigned)r->in_bytes, 0};
+        max_hyp = std::max(max_hyp, r->P.n_hyp);
+    }
+    EK(stage_in(C, D, batch.size(), 2));
+    EK(launch_pnp_batch(C.s, D.dprob, (int)batch.size(), max_hyp));
+    SYNC_TIMED(C);   // the refit kernel wrote every result straight into the request's pinned block
+}
+
+void process_ba(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
+    // one launch chain per distinct iteration cap (in practice one)
+    std::vector<int> iters;
+    for (Req* q : batch) { const int it = ((BAReq*)q)->max_iterations; if (std::find(iters.begin(), iters.end(), it) == iters.end()) iters.push_back(it); }
+    std::vector<BAReq*> sorted;
+    for (int it : iters) for (Req* q : batch) if (((BAReq*)q)->max_iterations == it) sorted.push_back((BAReq*)q);
+    DescBlock<BAProb> D;
+    EK(desc_block(C, sorted.size(), D));
+    for (size_t i = 0; i < sorted.size(); i++) {
+        BAReq* r = sorted[i];
+        ba_fill_prob(D.hprob[i], r->A, r->b->d_bastate, r->b->d_bapart);
+        D.hjobs[i] = StageJob{(const char*)r->b->d_h_stage, r->b->d_ba_io, (unsigned)r->io_bytes, 0};
+    }
+    EK(stage_in(C, D, sorted.size(), 8));
+    size_t i0 = 0;
+    for (int it : iters) {
+        BABatchDims dims{0, 0, 0, 0, 0, 0, it};
+        size_t i1 = i0;
+        while (i1 < sorted.size() && sorted[i1]->max_iterations == it) {
+            const BAProb& P = D.hprob[i1];
+            dims.max_eval_blocks = std::max(dims.max_eval_blocks, P.nbo + P.clear_blocks);
+            dims.max_nc = std::max(dims.max_nc, P.A.nc); dims.max_nbp = std::max(dims.max_nbp, P.nbp); dims.max_tiles = std::max(dims.max_tiles, P.tiles);
+            dims.max_m = std::max(dims.max_m, 6 * P.A.nc);
+            i1++;
+        }
+        dims.n_probs = (int)(i1 - i0);
+        EK(launch_ba_multi_batch(C.s, D.dprob + i0, dims));
+        i0 = i1;
+    }
+    SYNC_TIMED(C);
+}
+
+void process_dlt(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
+    DescBlock<DltProblem> D;
+    EK(desc_block(C, batch.size(), D));
+    int max_n = 0;
+    for (size_t i = 0; i < batch.size(); i++) {
+        DltReq* r = (DltReq*)batch[i];
+        D.hprob[i] = r->P;
+        D.hjobs[i] = StageJob{(const char*)r->b->d_h_stage, r->b->d_tri_in, (unsigned)r->in_bytes, 0};
+        max_n = std::max(max_n, r->P.n);
+    }
+    EK(stage_in(C, D, batch.size(), 2));
+    EK(launch_tri_dlt_batch(C.s, D.dprob, (int)batch.size(), max_n));
+    SYNC_TIMED(C);
+}
+
+void combiner_loop(BatchEngine* E, int role) {
+    Combiner* C = &E->comb[role];
     (void)hipSetDevice(E->ctx->device);
     tl_prof = &E->ctx->prof;
     for (;;) {
         std::vector<Req*> batch;
+        const auto ti = std::chrono::steady_clock::now();
         {
             std::unique_lock<std::mutex> lk(C->mu);
             C->cv_new.wait(lk, [&] { return !C->pending.empty() || C->stop; });
@@ -294,13 +370,22 @@ void combiner_loop(BatchEngine* E, Combiner* C, bool is_front) {
             }
             batch.swap(C->pending);
         }
-        if (is_front) process_front(E, batch); else process_back(E, batch);
+        const auto tw = std::chrono::steady_clock::now();
+        C->t_idle += std::chrono::duration<double>(tw - ti).count();
+        switch (role) {
+        case R_LK: process_lk(E, *C, batch); break;
+        case R_DET: process_det(E, *C, batch); break;
+        case R_PNP: process_pnp(E, *C, batch); break;
+        case R_BA: process_ba(E, *C, batch); break;
+        default: process_dlt(E, *C, batch); break;
+        }
         {
             std::lock_guard<std::mutex> lk(C->mu);
-            for (Req* r : batch) r->done = true;
             C->batches++; C->requests += (long)batch.size();
+            for (Req* r : batch) { r->done = true; r->cv.notify_one(); }   // after this the owner may destroy the request
         }
-        C->cv_done.notify_all();
+        C->t_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+        { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); C->t_cpu = ts.tv_sec + 1e-9 * ts.tv_nsec; }
     }
 }
 
@@ -309,7 +394,7 @@ int submit(pmv_ctx* ctx, Combiner& C, Req* r) {
         std::unique_lock<std::mutex> lk(C.mu);
         C.pending.push_back(r);
         C.cv_new.notify_one();
-        C.cv_done.wait(lk, [&] { return r->done; });
+        r->cv.wait(lk, [&] { return r->done; });
     }
     if (r->rc != PMV_OK) set_err(ctx, "%s", r->err);
     return r->rc;
@@ -323,14 +408,16 @@ int submit(pmv_ctx* ctx, Combiner& C, Req* r) {
 void batch_engine_destroy(pmv_ctx* ctx) {
     BatchEngine* E = ctx->engine;
     if (!E) return;
-    for (Combiner* C : {&E->front, &E->back}) {
-        { std::lock_guard<std::mutex> lk(C->mu); C->stop = true; }
-        C->cv_new.notify_all();
-        if (C->th.joinable()) C->th.join();
+    for (Combiner& C : E->comb) {
+        { std::lock_guard<std::mutex> lk(C.mu); C.stop = true; }
+        C.cv_new.notify_all();
+        if (C.th.joinable()) C.th.join();
+        if (C.s) { (void)hipStreamSynchronize(C.s); (void)hipStreamDestroy(C.s); }
+        if (C.ev) (void)hipEventDestroy(C.ev);
+        C.h_desc.release(); C.d_desc.release();
     }
     for (BackendBuffers* b : E->slots) backend_free(b);
-    for (Growable* g : {&E->h_front, &E->d_front, &E->h_cells, &E->d_cells, &E->d_eig, &E->d_cellmax, &E->d_det_xy, &E->d_det_score, &E->d_det_count, &E->h_det,
-                        &E->h_desc, &E->d_desc}) g->release();
+    for (Growable* g : {&E->h_front, &E->d_front, &E->h_cells, &E->d_cells, &E->d_eig, &E->d_cellmax, &E->d_det_xy, &E->d_det_score, &E->d_det_count, &E->h_det}) g->release();
     if (E->h_out_xy) (void)hipHostFree(E->h_out_xy);
     if (E->h_err) (void)hipHostFree(E->h_err);
     if (E->h_status) (void)hipHostFree(E->h_status);
@@ -362,14 +449,21 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
     CKC(hipHostGetDevicePointer((void**)&E->dm_status, E->h_status, 0));
     CKC(hipHostGetDevicePointer((void**)&E->dm_err, E->h_err, 0));
     CKC(hipMalloc(&E->d_flags, 16));
-    E->front.th = std::thread(combiner_loop, E, &E->front, true);
-    E->back.th = std::thread(combiner_loop, E, &E->back, false);
+    for (int r = 0; r < R_COUNT; r++) {
+        CKC(hipStreamCreateWithFlags(&E->comb[r].s, hipStreamNonBlocking));
+        CKC(hipEventCreateWithFlags(&E->comb[r].ev, hipEventBlockingSync | hipEventDisableTiming));
+    }
+    if (const char* e = getenv("PMV_BATCH_WAIT")) E->wait_mode = !strcmp(e, "spin") ? 0 : !strcmp(e, "yield") ? 1 : 2;
+    for (int r = 0; r < R_COUNT; r++) E->comb[r].th = std::thread(combiner_loop, E, r);
     *out = E;
     return PMV_OK;
 }
 
-void batch_engine_stats(BatchEngine* E, long* out4) {
-    out4[0] = E->front.batches; out4[1] = E->front.requests; out4[2] = E->back.batches; out4[3] = E->back.requests;
+void batch_engine_stats(BatchEngine* E, long long* counts10, double* times15) {
+    for (int r = 0; r < R_COUNT; r++) {
+        counts10[2 * r] = E->comb[r].batches; counts10[2 * r + 1] = E->comb[r].requests;
+        if (times15) { times15[3 * r] = E->comb[r].t_cpu; times15[3 * r + 1] = E->comb[r].t_work; times15[3 * r + 2] = E->comb[r].t_sync; }
+    }
 }
 
 // ---- request entry points (called from the sequences' own host threads) ---------------------------------------------------------
@@ -391,7 +485,7 @@ int engine_lk(BatchEngine* E, int prev_slot, int next_slot, const float* prev_xy
         const int s8 = (int)((long)i * 8 / n), first = (int)(((long)s8 * n + 7) / 8);
         r.order[(i - first) * 8 + s8] = byx[i].second;
     }
-    return submit(ctx, E->front, &r);
+    return submit(ctx, E->comb[R_LK], &r);
 }
 
 int engine_detect(BatchEngine* E, int kind, int slot, const int* cells, int n_cells, int max_per_cell, double quality, double min_dist, int* out_xy,
@@ -411,7 +505,7 @@ int engine_detect(BatchEngine* E, int kind, int slot, const int* cells, int n_ce
             PMV_ERR_INVALID, "detect: cell %d invalid", i);
     }
     r.quality = quality; r.min_dist = min_dist; r.out_xy = out_xy; r.out_score = out_score; r.out_count = out_count;
-    return submit(ctx, E->front, &r);
+    return submit(ctx, E->comb[R_DET], &r);
 }
 
 int engine_pnp(BatchEngine* E, int seq, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec, int iterations,
@@ -422,7 +516,7 @@ int engine_pnp(BatchEngine* E, int seq, const float* obj_xyz, const float* img_x
     PnPReq r;
     r.kind = 10; r.b = E->slots[seq];
     pnp_prepare(r.b, obj_xyz, img_xy, m, K, iterations, reproj_err, confidence, &r.P, &r.in_bytes);
-    rc = submit(ctx, E->back, &r);
+    rc = submit(ctx, E->comb[R_PNP], &r);
     if (rc) return rc;
     pnp_finish(ctx, r.b, obj_xyz, img_xy, m, K, rvec, tvec, iterations, reproj_err, confidence, r.in_bytes, out_inliers, out_n_inliers);
     return PMV_OK;
@@ -438,7 +532,7 @@ int engine_ba(BatchEngine* E, int seq, double* cams, int nc, double* pts, int np
     r.kind = 11; r.b = E->slots[seq]; r.max_iterations = max_iterations;
     rc = ba_prepare(ctx, r.b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, true, &r.A, &r.io_bytes);
     if (rc) return rc;
-    rc = submit(ctx, E->back, &r);
+    rc = submit(ctx, E->comb[R_BA], &r);
     if (rc) return rc;
     ba_finish(ctx, r.b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, nullptr);
     return PMV_OK;
@@ -451,7 +545,7 @@ int engine_dlt(BatchEngine* E, int seq, const double* q1, const double* q2, int 
     DltReq r;
     r.kind = 12; r.b = E->slots[seq];
     dlt_prepare(r.b, q1, q2, n, P1x4, mask_in, &r.P, &r.in_bytes);
-    const int rc = submit(ctx, E->back, &r);
+    const int rc = submit(ctx, E->comb[R_DLT], &r);
     if (rc) return rc;
     dlt_finish(ctx, r.b, q1, q2, n, P1x4, mask_in, r.in_bytes, out_Q, out_mask, out_good);
     return PMV_OK;

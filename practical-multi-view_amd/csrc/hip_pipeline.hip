@@ -298,12 +298,12 @@ int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* param
         }
     return PMV_OK;
 }
-// diagnostic: launches and requests the two combiners have served so far {front batches, front requests, back batches, back requests}
-int pmv_batch_stats(pmv_ctx* ctx, long long* out4) {
-    if (!ctx || !out4) return PMV_ERR_INVALID;
-    long v[4] = {0, 0, 0, 0};
-    if (ctx->engine) pmv::batch_engine_stats(ctx->engine, v);
-    for (int i = 0; i < 4; i++) out4[i] = v[i];
+// diagnostic: what the five combiners (LK, detectors, PnP, BA, DLT) have served so far
+int pmv_batch_stats(pmv_ctx* ctx, long long* counts10, double* times15) {
+    if (!ctx || !counts10) return PMV_ERR_INVALID;
+    for (int i = 0; i < 10; i++) counts10[i] = 0;
+    if (times15) for (int i = 0; i < 15; i++) times15[i] = 0;
+    if (ctx->engine) pmv::batch_engine_stats(ctx->engine, counts10, times15);
     return PMV_OK;
 }
 void pmv_pipeline_free(pmv_pipeline_result* r) { delete r; }

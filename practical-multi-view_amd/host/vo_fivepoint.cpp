@@ -569,7 +569,9 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     double E[9];
     int drawn = 0;
     auto tE = std::chrono::steady_clock::now();
+    HostCpuScope* cpu_e = new HostCpuScope(tracker->stats.hp.t[14]);
     const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn, pool.get(), workers);
+    delete cpu_e;
     if (pool) pool->end();
     tracker->stats.t_tri_essential += std::chrono::duration<double>(std::chrono::steady_clock::now() - tE).count();
     tracker->stats.tri_hypotheses += drawn;

@@ -313,6 +313,7 @@ void OdometryPipeline::initialise() {   // :428-482
 }
 
 void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
+    HostCpuScope cpu_(stats.hp.t[12]);
     frame.frame = (int)frames.size();
     const auto tl0 = std::chrono::steady_clock::now();
     fmap feat_corr = matcher->matchFeatures(*(frames[frame.frame - 1]), frame);
@@ -361,6 +362,7 @@ void OdometryPipeline::motionHeuristics(Mat3& _R, Vec3& _t, int j) {   // :171-2
 
 void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
     HostProfScope hp_total(stats.hp.t[8]);
+    HostCpuScope cpu_(stats.hp.t[13]);
     const int j = src.frame;
     Mat3 _R = R[j];
     Vec3 _t = t[j];
@@ -381,6 +383,7 @@ void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
     // (frames[src.frame], frames[next.frame] are updated in place; the reference works on copies and writes them back)
     if (cfg.bundle_size && src.frame && src.frame % (cfg.bundle_size / 3 * 2) == 0) {
         const auto t1 = tnow();
+        HostCpuScope cpu_ba(stats.hp.t[15]);
         ba->apply(next);
         stats.t_ba += secs(t1);
     }

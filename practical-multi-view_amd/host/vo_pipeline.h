@@ -11,6 +11,7 @@
 #include <chrono>
 #include <list>
 #include <mutex>
+#include <time.h>
 
 namespace vo {
 
@@ -96,13 +97,20 @@ private:
 
 // optional section timers of the host adapters (PMV_HOST_PROF=1 prints them to stderr at the end of a run)
 struct HostProf {
-    static constexpr int N = 12;
+    static constexpr int N = 16;
     double t[N] = {0};
     static const char* name(int i) {
         static const char* n[N] = {"pnp_gather", "pnp_scatter", "ba_gather", "ba_scatter", "tri_gather", "tri_landmarks", "heuristics",
-                                   "count3d", "estimatePose", "backend_wait", "frontend_total", "init"};
+                                   "count3d", "estimatePose", "backend_wait", "frontend_total", "init",
+                                   "cpu_addFrame", "cpu_estimatePose", "cpu_fivepoint", "cpu_ba_apply"};   // thread CPU seconds (not wall)
         return n[i];
     }
+};
+struct HostCpuScope {   // CPU time of the calling thread spent inside the scope (blocked waits do not count)
+    double& acc; double t0;
+    static double now() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    explicit HostCpuScope(double& a) : acc(a), t0(now()) {}
+    ~HostCpuScope() { acc += now() - t0; }
 };
 struct HostProfScope {
     double& acc; std::chrono::steady_clock::time_point t0;

@@ -1,0 +1,48 @@
+"""throughput of pmv_pipeline_run_batch for several batch sizes (diagnostic; bench.py reports the chosen one)
+usage: python scripts/bench_batch.py [B ...]"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import numpy as np
+if os.environ.get("PIN"):
+    cpus = sorted(os.sched_getaffinity(0))[:int(os.environ["PIN"])]
+    os.sched_setaffinity(0, cpus)
+    print("pinned to CPUs", cpus, flush=True)
+pmv = importlib.import_module("practical-multi-view_amd")
+cfg = dict(w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157)
+n = int(os.environ.get("FRAMES", "1101"))
+Bs = [int(x) for x in sys.argv[1:]] or [8, 16, 32]
+frames, gt = pmv.synth_sequence(1007, 0, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16)
+K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+Bmax = max(Bs)
+ctx = pmv.Context(cfg["w"], cfg["h"], n_slots=Bmax * n, max_tracks=1024, max_ba_cams=8, max_ba_points=2048, max_ba_obs=16384)
+for b in range(Bmax):
+    ctx.frames_stage(b * n, frames)
+ref = None
+THREADED = int(os.environ.get("THREADED", "1"))
+print("wait mode", os.environ.get("PMV_BATCH_WAIT", "block"), "threaded", THREADED, flush=True)
+for B in Bs:
+    seqs = [(b * n, n, gt) for b in range(B)]
+    r = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED)   # warm-up
+    ctx.sync()
+    s0 = ctx.batch_stats()
+    t0 = time.perf_counter()
+    c0 = time.process_time()
+    r2 = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    cpu = time.process_time() - c0
+    s1 = ctx.batch_stats()
+    fr = sum(n - int(x.stats["init_offset"]) for x in r2)
+    if ref is None:
+        ref = r2[0].poses
+    same = all(np.array_equal(x.poses, ref) for x in r2)
+    print(f"B={B:3d}: {fr / dt:9.1f} frames/s  ({dt:.3f} s)  identical={same}  process CPU {cpu:.2f} s = {cpu / fr * 1e6:.0f} us per frame, {cpu / dt:.1f} cores busy", flush=True)
+    for role in s1:
+        d = {k: s1[role][k] - s0[role][k] for k in s1[role]}
+        if d["launches"]:
+            print(f"        {role:4s} {d['requests'] / d['launches']:5.1f} req/launch, {d['launches']:5d} launches, cpu {d['cpu_s']:.2f} s, work {d['work_s']:.2f} s (sync {d['sync_s']:.2f} s)"
+                  f"  -> {d['work_s'] / d['launches'] * 1e6:.0f} us per round", flush=True)
+    for x in r + r2:
+        x.free()
+ctx.close()
