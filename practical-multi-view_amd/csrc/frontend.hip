@@ -99,30 +99,40 @@ __device__ inline void bilinear_weights(float a, float b, int& w00, int& w01, in
 // DPP reduction per value instead of the hi/lo int32 pair. Each wavefront leaves its total in LDS and after ONE barrier every
 // thread adds the four totals. `slot` alternates between calls that are not separated by another barrier (iteration parity),
 // so the next write never overtakes a pending read. (float)(total) rounds the exact integer once, like (float)(int64).
-constexpr int LK_T = 256, LK_NW = LK_T / 64;
-template <int N>
-__device__ inline void block_sum_exact(const int (&part)[N], double (&out)[N], double* sred /* [2][LK_NW][4] */, int slot) {
+// T = threads per track: 256 (four wavefronts: the shortest chain per track, used when one sequence's ~300 tracks are all there is)
+// or 64 (one wavefront: no barrier in the reduction and four times as many tracks resident per CU — the throughput form used by the
+// batched launch, where thousands of tracks are in flight). Integer sums are exact, so both give the same bits.
+constexpr int LK_T = 256;
+template <int N, int T>
+__device__ inline void block_sum_exact(const int (&part)[N], double (&out)[N], double* sred /* [2][T/64][4] */, int slot) {
+    constexpr int NW = T / 64;
+    if (NW == 1) {
+#pragma unroll
+        for (int k = 0; k < N; k++) out[k] = wave_sum_f64((double)part[k]);
+        return;
+    }
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < N; k++) {
         const double v = wave_sum_f64((double)part[k]);
-        if (lane == 0) sred[(slot * LK_NW + wv) * 4 + k] = v;
+        if (lane == 0) sred[(slot * NW + wv) * 4 + k] = v;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        double a = sred[(slot * LK_NW + 0) * 4 + k];
+        double a = sred[(slot * NW + 0) * 4 + k];
 #pragma unroll
-        for (int w = 1; w < LK_NW; w++) a += sred[(slot * LK_NW + w) * 4 + k];
+        for (int w = 1; w < NW; w++) a += sred[(slot * NW + w) * 4 + k];
         out[k] = a;
     }
 }
 
-// 64x64-byte search tile, dword copies (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0): 1024 dwords over 256 threads
+// 64x64-byte search tile, dword copies (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0): 1024 dwords over T threads
+template <int T>
 __device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0, int ty0, int tid) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int idx = tid + q * LK_T, row = idx >> 4, xw = idx & 15;
+    for (int q = 0; q < 1024 / T; q++) {
+        const int idx = tid + q * T, row = idx >> 4, xw = idx & 15;
         ((uint32_t*)(sJ + row * SJ_STRIDE))[xw] = *(const uint32_t*)(Jorg + (ptrdiff_t)(ty0 + row) * js + tx0 + 4 * xw);
     }
 }
@@ -134,14 +144,16 @@ __device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0
 // One track through all pyramid levels; executed by one whole 256-thread block (every thread gets the same results). `stamp_on`:
 // this block feeds the diagnostic phase timers.
 struct LKResult { float x, y, err; int status, n_iter, n_lev; };
+template <int T>
 __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS, const PyrLayout& L,
                                                    const float px0, const float py0, const LKParams& P, const bool stamp_on) {
     __shared__ __attribute__((aligned(16))) uint8_t sI[35 * SI_STRIDE];
     __shared__ __attribute__((aligned(16))) short2 sD[33 * SD_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t sJ[64 * SJ_STRIDE];
-    __shared__ double sred[2 * LK_NW * 4];
+    __shared__ double sred[2 * (T / 64) * 4];
+    constexpr int TPR = T / 32, PP = 32 / TPR;   // threads per window row, pixels per thread (256 -> 8 x 4, 64 -> 2 x 16)
     const int tid = threadIdx.x;
-    const int r = tid >> 3, c0 = (tid & 7) * 4;
+    const int r = tid / TPR, c0 = (tid % TPR) * PP;
     const int W = LK_WIN;
     const float half = 15.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
@@ -177,7 +189,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
         // ---- stage the 35x35 I tile (rows ipy-1 .. ipy+33, cols ipx-1 .. ipx+33, always inside the padded buffer) as dword copies of
         // 40-byte rows that start at the 4-byte-aligned column below ipx-1 (35 + 3 <= 40 columns stay inside the 64-pixel frame)
         const int ax0 = (ipx - 1) & ~3, aoff = (ipx - 1) - ax0;
-        for (int idx = tid; idx < 35 * 10; idx += LK_T) {
+        for (int idx = tid; idx < 35 * 10; idx += T) {
             const int y = idx / 10, xw = idx - y * 10;
             ((uint32_t*)(sI + y * SI_STRIDE))[xw] = *(const uint32_t*)(Iorg + (ptrdiff_t)(ipy - 1 + y) * ls + ax0 + 4 * xw);
         }
@@ -185,7 +197,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
         const uint8_t* sIo = sI + aoff;   // tile origin (ipx-1, ipy-1)
         LSTAMP(1);
         // ---- Scharr (calcSharrDeriv) at the 33x33 sample positions; constant 0 outside the image
-        for (int idx = tid; idx < 33 * 33; idx += LK_T) {
+        for (int idx = tid; idx < 33 * 33; idx += T) {
             const int y = idx / 33, x = idx - y * 33;
             const uint8_t* c = &sIo[(y + 1) * SI_STRIDE + (x + 1)];
             const int gx = ipx + x, gy = ipy + y;
@@ -203,8 +215,8 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
         }
         __syncthreads();
         LSTAMP(2);
-        // ---- this thread's 4 window samples (I with 5 fractional bits, Ix, Iy) + exact A sums
-        int Iv[4], Ix[4], Iy[4];
+        // ---- this thread's PP window samples (I with 5 fractional bits, Ix, Iy) + exact A sums
+        int Iv[PP], Ix[PP], Iy[PP];
         int apart[3] = {0, 0, 0};
         {
             const uint8_t* i0 = &sIo[(r + 1) * SI_STRIDE + (c0 + 1)];
@@ -212,7 +224,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             int p0 = i0[0], p1 = i0[SI_STRIDE];
             short2 q0 = d0[0], q1 = d0[SD_STRIDE];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < PP; k++) {
                 const int p0n = i0[k + 1], p1n = i0[SI_STRIDE + k + 1];
                 const short2 q0n = d0[k + 1], q1n = d0[SD_STRIDE + k + 1];
                 // every factor fits 24 bits (pixels 8, weights 15, derivatives 13): v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter
@@ -225,7 +237,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             }
         }
         double sA[3];
-        block_sum_exact<3>(apart, sA, sred, slot); slot ^= 1;
+        block_sum_exact<3, T>(apart, sA, sred, slot); slot ^= 1;
         const float A11 = (float)sA[0] * FLT_SCALE, A12 = (float)sA[1] * FLT_SCALE, A22 = (float)sA[2] * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * W * W);
@@ -251,7 +263,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             if (!have_tile || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
                 tx0 = (inx - 16) & ~3; ty0 = iny - 16;
                 __syncthreads();
-                stage_J(sJ, Jorg, ls, tx0, ty0, tid);
+                stage_J<T>(sJ, Jorg, ls, tx0, ty0, tid);
                 __syncthreads();
                 have_tile = true;
                 wx = inx - tx0; wy = iny - ty0;
@@ -263,7 +275,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 const uint8_t* j0 = &sJ[(wy + r) * SJ_STRIDE + wx + c0];
                 int p0 = j0[0], p1 = j0[SJ_STRIDE];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < PP; k++) {
                     const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
                     const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
                     bpart[0] += __mul24(diff, Ix[k]); bpart[1] += __mul24(diff, Iy[k]);
@@ -272,7 +284,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             }
             LSTAMP(10);
             double sB[2];
-            block_sum_exact<2>(bpart, sB, sred, slot); slot ^= 1;
+            block_sum_exact<2, T>(bpart, sB, sred, slot); slot ^= 1;
             LSTAMP(11);
             const float fb1 = (float)sB[0] * FLT_SCALE, fb2 = (float)sB[1] * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
@@ -301,7 +313,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 if (!have_tile || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
                     tx0 = (inx - 16) & ~3; ty0 = iny - 16;
                     __syncthreads();
-                    stage_J(sJ, Jorg, ls, tx0, ty0, tid);
+                    stage_J<T>(sJ, Jorg, ls, tx0, ty0, tid);
                     __syncthreads();
                     wx = inx - tx0; wy = iny - ty0;
                 }
@@ -310,14 +322,14 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 const uint8_t* j0 = &sJ[(wy + r) * SJ_STRIDE + wx + c0];
                 int p0 = j0[0], p1 = j0[SJ_STRIDE];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < PP; k++) {
                     const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
                     const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
                     epart[0] += diff < 0 ? -diff : diff;
                     p0 = p0n; p1 = p1n;
                 }
                 double sE[1];
-                block_sum_exact<1>(epart, sE, sred, slot); slot ^= 1;
+                block_sum_exact<1, T>(epart, sE, sred, slot); slot ^= 1;
                 err = (float)sE[0] * (1.f / (32 * W * W));
             }
         }
@@ -345,20 +357,21 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
                                              float* __restrict__ out_err) {
     const int t = order[blockIdx.x];   // block -> track (XCD-aware order built by the host; -1 = no track)
     if (t < 0 || t >= n) return;
-    const LKResult r = lk_track_block(prevS, nextS, L, prev_xy[2 * t], prev_xy[2 * t + 1], P, t == 0);
+    const LKResult r = lk_track_block<LK_T>(prevS, nextS, L, prev_xy[2 * t], prev_xy[2 * t + 1], P, t == 0);
     lk_store(r, t, P, out_xy, out_status, out_err);
 }
 
 // Batched form ("same kernels with a leading batch dimension"): the blocks of several independent sequences in one
 // launch. seqs[q] = byte offsets of the prev / next frame slots of sequence q inside `slots`; blocks[b] = (q, track) with track
 // indexing the concatenated coordinate / result arrays (-1 = padding block). All sequences share the frame geometry L.
-__global__ __launch_bounds__(LK_T) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
+constexpr int LKB_T = 64;   // one wavefront per track: throughput form (see block_sum_exact)
+__global__ __launch_bounds__(LKB_T) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
                                                    PyrLayout L, const float* __restrict__ prev_xy, LKParams P, float* __restrict__ out_xy,
                                                    uint8_t* __restrict__ out_status, float* __restrict__ out_err) {
     const int2 bt = blocks[blockIdx.x];
     if (bt.y < 0) return;
     const LKSeq sq = seqs[bt.x];
-    const LKResult r = lk_track_block(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, false);
+    const LKResult r = lk_track_block<LKB_T>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, false);
     lk_store(r, bt.y, P, out_xy, out_status, out_err);
 }
 
@@ -378,7 +391,7 @@ hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_s
     if (n_blocks <= 0) return hipSuccess;
     if (!slots || !d_seqs || !d_blocks || !d_prev_xy || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     ProfScope ps(K_LK, s);
-    hipLaunchKernelGGL(k_lk_batch, dim3(n_blocks), dim3(LK_T), 0, s, slots, d_seqs, d_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err);
+    hipLaunchKernelGGL(k_lk_batch, dim3(n_blocks), dim3(LKB_T), 0, s, slots, d_seqs, d_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err);
     return hipGetLastError();
 }
 
