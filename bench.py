@@ -155,7 +155,9 @@ def main():
     t_gen = time.time() - t0
     n_max = max(f.shape[0] for f, _ in data)
     ba_cams = max(32, cfg["bundle_size"] + 2)
-    ctx_kw = dict(n_slots=n_max, max_tracks=4096, max_ba_cams=ba_cams, max_ba_points=8192, max_ba_obs=65536, device=local_rank)
+    big = cfg["min_tracked"] > 1000   # configs[3]: 2000 tracks x bundle 20 -> up to ~9 k window landmarks, ~55 k observations
+    ctx_kw = dict(n_slots=n_max, max_tracks=8192 if big else 4096, max_ba_cams=ba_cams, max_ba_points=32768 if big else 8192,
+                  max_ba_obs=262144 if big else 65536, device=local_rank)
     # one context (streams + HBM frame slots) per sequence of this rank: inputs resident in HBM before the timed region
     ctxs = []
     for frames, _ in data:

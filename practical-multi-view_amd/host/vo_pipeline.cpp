@@ -6,6 +6,8 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <atomic>
+#include <exception>
 #include <cfloat>
 
 namespace vo {
@@ -418,25 +420,34 @@ void OdometryPipeline::run_threaded() {
     std::condition_variable cv;
     std::deque<int> jobs;
     bool done = false;
-    std::vector<std::shared_ptr<Frame>> shared_frames;   // stable snapshot pointers for the back-end
+    // a plugin error (e.g. a capacity error of the device library) in either thread ends the run and is rethrown to the caller
+    std::exception_ptr back_error;
+    std::atomic<bool> failed{false};
     std::thread back([&]() {
-        for (;;) {
-            int j;
-            std::shared_ptr<Frame> a, b;
-            {
-                HostProfScope hp_wait(stats.hp.t[9]);
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !jobs.empty() || done; });
-                if (jobs.empty()) return;
-                j = jobs.front(); jobs.pop_front();
-                a = frames[j]; b = frames[j + 1];
+        try {
+            for (;;) {
+                int j;
+                std::shared_ptr<Frame> a, b;
+                {
+                    HostProfScope hp_wait(stats.hp.t[9]);
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !jobs.empty() || done; });
+                    if (jobs.empty()) return;
+                    j = jobs.front(); jobs.pop_front();
+                    a = frames[j]; b = frames[j + 1];
+                }
+                estimatePose(*a, *b);
             }
-            estimatePose(*a, *b);
+        } catch (...) {
+            back_error = std::current_exception();
+            failed.store(true);
         }
     });
+    std::exception_ptr front_error;
     const auto t_front0 = std::chrono::steady_clock::now();
+    try {
     for (int i = init_offset + 1; i < (int)images.size(); i++) {
-        if (i >= cfg.stop) break;
+        if (i >= cfg.stop || failed.load()) break;
         Frame frame(images[i]);
         if (frame.isEmpty()) continue;
         {
@@ -476,9 +487,12 @@ void OdometryPipeline::run_threaded() {
         }
         if (on_frame_added) on_frame_added(frame.frame);
     }
+    } catch (...) { front_error = std::current_exception(); }
     { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_one(); }
     stats.hp.t[10] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_front0).count();
     back.join();
+    if (front_error) std::rethrow_exception(front_error);
+    if (back_error) std::rethrow_exception(back_error);
 }
 
 }  // namespace vo

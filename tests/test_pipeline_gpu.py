@@ -236,3 +236,23 @@ def test_streamed_ingest_is_bit_identical_to_staged_frames(pmv, gpu_ctx_factory)
         assert np.array_equal(x, y)
     for l in range(ctx.num_levels(n - 1) + 1):
         assert np.array_equal(ctx2.get_level(n - 1, l, cfg["w"], cfg["h"]), ctx.get_level(n - 1, l, cfg["w"], cfg["h"]))
+
+
+def test_plugin_error_in_the_backend_thread_is_returned_not_fatal(pmv, gpu_ctx_factory):
+    """a capacity error raised by a plugin call on the back-end host thread (here: BA workspace too small) ends the run and comes
+    back as the status of pmv_pipeline_run - threaded, sequential and batched"""
+    cfg, n = K07, 30
+    frames, poses = pmv.synth_sequence(1003, 0, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"])
+    K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096, max_ba_cams=8, max_ba_points=64, max_ba_obs=4096)
+    ctx.frames_stage(0, frames)
+    for threaded in (1, 0):
+        with pytest.raises(pmv.PmvError) as e:
+            ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=threaded)
+        assert e.value.code == -3 and "exceed capacity" in str(e.value)
+    with pytest.raises(pmv.PmvError) as e:
+        ctx.pipeline_run_batch([(0, n, poses)], cfg["w"], cfg["h"], K)
+    assert e.value.code == -3
+    ok = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096)      # and the library is still usable afterwards
+    ok.frames_stage(0, frames)
+    assert len(ok.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1).poses) > 10
