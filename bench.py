@@ -158,23 +158,28 @@ def main():
     big = cfg["min_tracked"] > 1000   # configs[3]: 2000 tracks x bundle 20 -> up to ~9 k window landmarks, ~55 k observations
     ctx_kw = dict(n_slots=n_max, max_tracks=8192 if big else 4096, max_ba_cams=ba_cams, max_ba_points=32768 if big else 8192,
                   max_ba_obs=262144 if big else 65536, device=local_rank)
-    # one context (streams + HBM frame slots) per sequence of this rank: inputs resident in HBM before the timed region
-    ctxs = []
-    for frames, _ in data:
-        c = pmv.Context(w, h, **dict(ctx_kw, n_slots=frames.shape[0]))
-        c.frames_stage(0, frames)
-        ctxs.append(c)
-    ctx = ctxs[0]
+    # inputs resident in HBM before the timed region. One sequence per rank: one context. Several sequences on a rank (configs[4] on
+    # fewer than 8 GPUs): ONE context holds them back to back and the step runs them together through the batch engine.
+    multi = len(data) > 1
+    seq_slots, first = [], 0
+    ctx = pmv.Context(w, h, **dict(ctx_kw, n_slots=sum(f.shape[0] for f, _ in data)))
+    for frames, gt_ in data:
+        ctx.frames_stage(first, frames)
+        seq_slots.append((first, frames.shape[0], gt_))
+        first += frames.shape[0]
+    ctxs = [ctx]
     tri_threads = 1 if args.sequential else max(1, min(args.tri_threads, ncpu - 2))
     run_kw = dict(min_tracked=cfg["min_tracked"], tol=cfg["tol"], init_frames=INIT_FRAMES, bundle_size=cfg["bundle_size"], ba_iterations=BA_ITERATIONS,
                   threaded=0 if args.sequential else 1, want_features=False, n_threads=tri_threads, defer_free=True)
 
     def step(host=False):
-        """one pass over the rank's sequences (one after the other); host=True: frames streamed from host memory"""
-        out = []
-        for c, (frames, gt) in zip(ctxs, data):
-            out.append(c.pipeline_run(frames.shape[0], w, h, K, gt, build_pyramids=1, host_frames=frames if host else None, **run_kw))
-        return out
+        """one pass over the rank's sequence(s); host=True: frames streamed from host memory (single sequence only)"""
+        if multi:
+            return ctx.pipeline_run_batch(seq_slots, w, h, K, min_tracked=cfg["min_tracked"], tol=cfg["tol"], init_frames=INIT_FRAMES,
+                                          bundle_size=cfg["bundle_size"], ba_iterations=BA_ITERATIONS, want_features=False, defer_free=True,
+                                          threaded=0 if args.sequential else 1)
+        frames, gt = data[0]
+        return [ctx.pipeline_run(frames.shape[0], w, h, K, gt, build_pyramids=1, host_frames=frames if host else None, **run_kw)]
 
     def sync_all():
         for c in ctxs:
@@ -237,11 +242,12 @@ def main():
     if args.warmup > 0:
         ctx.prof_enable(True)
         ctx.prof_select(["k_bam_eval0", "k_bam_campoint", "k_bam_gemm", "k_bam_solve", "k_bam_backsub", "k_bam_finish"])
-        r_ = ctxs[0].pipeline_run(data[0][0].shape[0], w, h, K, data[0][1], build_pyramids=1, **run_kw)
+        rs_ = step()
         ctx.sync()
         ctx.prof_enable(False)
         prof_chain = ctx.prof_read()
-        r_.free()
+        for r_ in rs_:
+            r_.free()
 
     # critical path of one sequence = the back-end's serial chain (PnP(k+1) needs BA(k)'s landmarks; the front-end overlaps it):
     # the single kernel with the most time ON THAT CHAIN is the one reported
@@ -263,7 +269,7 @@ def main():
     prof_timed = ctx.prof_read()
     res = last_res[0]
     host_leg = None
-    if not args.no_host_leg:
+    if not args.no_host_leg and not multi:
         el_h, tot_h, last_h = timed(host=True)
         if rank == 0:
             same = all(np.array_equal(a.poses, b.poses) for a, b in zip(last_h, last_res))
@@ -391,7 +397,7 @@ def main():
         dt_wall = time.perf_counter() - t1
         dt = float(o.stats["seconds"])   # the pipeline run itself (setup, result extraction and teardown excluded, as for the GPU value)
         # the baseline computes the same thing: every 2-D feature of every frame equals the GPU run's (one extra, untimed GPU run)
-        gfe = ctxs[0].pipeline_run(m, w, h, K, gt[:m], **dict(run_kw, want_features=True, defer_free=False))
+        gfe = ctx.pipeline_run(m, w, h, K, gt[:m], **dict(run_kw, want_features=True, defer_free=False))
         feats_same = len(gfe.features) == len(o.features) and all(np.array_equal(a[:, :2], b[:, :2]) for a, b in zip(gfe.features, o.features))
         bad = np.nonzero(np.abs(gfe.poses - o.poses).max(axis=1) > 1e-6)[0]
         cpu = dict(value=round((m - int(o.stats["init_offset"])) / dt, 3), unit="frames/s", cores=nthr + 1, kind="port", flags=flags, cpu_model=cpu_model(),
