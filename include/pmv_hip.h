@@ -11,6 +11,8 @@
  *   pmv_detect_shitomasi                   ShiTomasiFeatureExtractor::extractFeatures    (ShiTomasiFeatureExtractor.cpp:5-75,
  *                                          Frame.cpp:58-86,119-138)                      -> BaseFeatureExtractor.h:21
  *   pmv_lk_track                           cv::calcOpticalFlowPyrLK                      (OpenCVLucasKanadeFM.cpp:15) -> BaseFeatureMatcher.h:22
+ *   pmv_knn_match                          kNNFeatureMatcher::matchFeatures' arithmetic   (kNNFeatureMatcher.cpp:13-31,63-122) -> BaseFeatureMatcher.h:22
+ *   pmv_detect_fast                        cv::FAST                                      (OpenCVFASTFeatureExtractor.cpp:8) -> BaseFeatureExtractor.h:21
  *   pmv_pnp_ransac                         cv::solvePnPRansac                            (OpenCVEPnPSolver.cpp:35-36) -> BasePnPSolver.h:19
  *   pmv_triangulate_candidates             cv::recoverPose (triangulation + cheirality)  (OpenCVFivePointTri.cpp:27) -> BaseTriangulator.h
  *   pmv_ba_residuals / pmv_ba_solve        ProjectionResidual + ceres::Solve             (ProjectionResidual.h:38-58,
@@ -89,7 +91,23 @@ int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, 
 int pmv_debug_gftt_response(pmv_ctx* ctx, int slot, const int* cell, float* out);
 int pmv_debug_shitomasi_response(pmv_ctx* ctx, int slot, const int* cell, double* out);
 
+/* cv::FAST(cell, kp, threshold, nonmax) (OpenCVFASTFeatureExtractor.cpp:8; 9_16 pattern) on sub-views of the frame in `slot`; a
+ * "cell" here may be as large as the frame (kNNFeatureMatcher.cpp:11 calls the extractor on the whole next frame). out_xy:
+ * n_cells * max_per_cell * 2 ints, cell-local (x, y) in cv::FAST's raster order, first max_per_cell kept as the adapter does
+ * (:10-18; max_per_cell <= 0 keeps nothing); out_response: n_cells * max_per_cell floats (the keypoint response = corner score,
+ * 0 without non-maximum suppression). */
+int pmv_detect_fast(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int max_per_cell, int threshold, int nonmax, int* out_xy,
+                    float* out_response, int* out_count);
+
 /* ---- feature matching ----------------------------------------------------------------------------- */
+/* The arithmetic of kNNFeatureMatcher::matchFeatures (kNNFeatureMatcher.cpp:13-31): for each of the n source features (x, y in
+ * src_slot's frame) the n_neighbours nearest of the m candidates (x, y in cmp_slot's frame; getNearestNeighbors :63-101 incl. its
+ * repeat-the-last-pick and default-(0,0) quirks) are compared through compareFeatures' pixel window (:103-122) and the best fit is
+ * chosen by the sequential `_err < err || err == 0` rule. out_best: n indices into the candidates (-1 = the default Feature at
+ * (0,0)); out_err: n floats. Thresholding, displacement statistics and the maps stay in the caller's adapter (:32-60).
+ * The reference's constants: n_neighbours 7, window 15. */
+int pmv_knn_match(pmv_ctx* ctx, int src_slot, int cmp_slot, const int* src_xy, int n, const int* cmp_xy, int m, int n_neighbours, int window,
+                  int* out_best, float* out_err);
 /* Pyramidal LK from frame slot `prev_slot` to `next_slot`. prev_xy: n*2 floats. out_xy n*2 floats,
  * out_status n bytes, out_err n floats (exactly the three outputs of cv::calcOpticalFlowPyrLK). */
 int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy,
@@ -171,10 +189,11 @@ int pmv_prof_read(pmv_ctx* ctx, int id, int* launches, double* total_ms, double*
 typedef struct pmv_pipeline_params {
     int n_frames, w, h;
     int min_tracked_features, tracked_features_tol, init_frames, bundle_size, ba_iterations;
-    int extractor;      /* 0 = goodFeaturesToTrack (reference default), 1 = ShiTomasi */
+    int extractor;      /* 0 = goodFeaturesToTrack (reference default), 1 = ShiTomasi, 2 = FAST (OpenCVFASTFeatureExtractor) */
     int threaded;       /* 0 = sequential schedule, 1 = front-end / back-end host threads (the reference's two threads) */
     int n_threads;      /* host threads that evaluate the triangulator's five-point RANSAC hypotheses side by side (>= 1; results do not depend on it) */
     int build_pyramids; /* rebuild the pyramids of slots 0..n_frames-1 inside the call */
+    int matcher;        /* 0 = pyramidal LK (reference default), 1 = kNNFeatureMatcher over `extractor` */
 } pmv_pipeline_params;
 typedef struct pmv_pipeline_result pmv_pipeline_result;
 

@@ -11,6 +11,9 @@ int shitomasi_cell(const uint8_t* img, int W, int cx0, int cy0, int cw, int ch, 
                    double* out_score, double* R_out);
 int pnp_ransac(const float* obj, const float* img, int m, const double K[9], double rvec[3], double tvec[3], int max_iters,
                float reproj_err, double confidence, int* inliers, int* hyp_used);
+void knn_match(const uint8_t* src, const uint8_t* cmp, int w, int h, const int* src_xy, int n, const int* cmp_xy, int m, int n_nn, int window,
+               int* out_best, float* out_err);
+int fast9_cell(const uint8_t* img, int W, int cx0, int cy0, int cw, int ch, int threshold, bool nonmax, int max_kp, int* out_xy, float* out_response);
 struct BASummary { double initial_cost, final_cost; int iterations, successful_steps, termination; };
 int ba_solve(double* cams, int nc, double* pts, int np, const double* obs, const int* cam_idx, const int* pt_idx, int nobs,
              const double* K, double huber, int max_iterations, BASummary* sum);

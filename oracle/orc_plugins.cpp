@@ -43,6 +43,26 @@ struct CpuShiTomasi : ShiTomasiExtractorBase {
         }
     }
 };
+struct CpuFast : FastExtractorBase {
+    void fast(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out,
+              std::vector<std::vector<float>>& response) override {
+        out.assign(cells.size(), {});
+        response.assign(cells.size(), {});
+        if (max < 1) return;
+        std::vector<int> xy((size_t)max * 2);
+        std::vector<float> rs((size_t)max);
+        for (size_t k = 0; k < cells.size(); k++) {
+            const ImageView& c = cells[k];
+            const int n = orc::fast9_cell(c.host, c.full_w, c.x0, c.y0, c.w, c.h, threshold, nonmax, max, xy.data(), rs.data());
+            for (int i = 0; i < n; i++) { out[k].push_back({xy[2 * i], xy[2 * i + 1]}); response[k].push_back(rs[i]); }
+        }
+    }
+};
+struct CpuKnn : KnnFeatureMatcherBase {
+    void knn(const ImageView& src, const ImageView& next, const int* src_xy, int n, const int* cmp_xy, int m, int* best, float* err) override {
+        orc::knn_match(src.host, next.host, src.full_w, src.full_h, src_xy, n, cmp_xy, m, neighbours, window, best, err);
+    }
+};
 struct CpuLK : LucasKanadeFMBase {
     int nthreads = 1;
     orc::Pool* pool = nullptr;   // fast mode (cpu_baseline timing): padded-buffer LK on a persistent pool, bit-identical results
@@ -88,9 +108,11 @@ void* orc_pipeline_run(const vo::PipelineParams* P, const uint8_t* frames, const
     std::unique_ptr<orc::Pool> pool, ba_pool;
     if (P->reserved & 1) { pool.reset(new orc::Pool(std::max(0, P->n_threads - 1))); ba_pool.reset(new orc::Pool(3)); }
     vo::BaseFeatureExtractor* ex;
-    if (P->extractor == 1) ex = new CpuShiTomasi(); else { auto* g = new CpuGftt(); g->pool = pool.get(); ex = g; }
+    if (P->extractor == 1) ex = new CpuShiTomasi(); else if (P->extractor == 2) ex = new CpuFast(); else { auto* g = new CpuGftt(); g->pool = pool.get(); ex = g; }
     run->owned_ex.push_back(ex);
-    auto* lk = new CpuLK(); lk->nthreads = P->n_threads; lk->pool = pool.get();
+    vo::BaseFeatureMatcher* lk;
+    if (P->matcher == 1) { auto* k = new CpuKnn(); k->extractor = ex; lk = k; }
+    else { auto* l = new CpuLK(); l->nthreads = P->n_threads; l->pool = pool.get(); lk = l; }
     // the back-end thread evaluates BA residuals on 4 threads of the same pool (CeresBundleAdjustment.cpp:58)
     orc::ba_set_pool(ba_pool.get(), 4);
     auto* pnp = new CpuPnP(); pnp->tracker = &run->pipe;

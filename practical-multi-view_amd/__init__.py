@@ -35,7 +35,7 @@ class BaSummary(C.Structure):
 ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
     "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_num_levels",
-    "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
+    "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_detect_fast", "pmv_knn_match", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates",
     "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
     "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_lk_counters", "pmv_prof_kernel_name", "pmv_prof_read",
@@ -51,7 +51,7 @@ class PipelineParams(C.Structure):
     _fields_ = [("n_frames", C.c_int), ("w", C.c_int), ("h", C.c_int), ("min_tracked_features", C.c_int),
                 ("tracked_features_tol", C.c_int), ("init_frames", C.c_int), ("bundle_size", C.c_int),
                 ("ba_iterations", C.c_int), ("extractor", C.c_int), ("threaded", C.c_int), ("n_threads", C.c_int),
-                ("build_pyramids", C.c_int)]
+                ("build_pyramids", C.c_int), ("matcher", C.c_int)]
 
 
 STAT_KEYS = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
@@ -279,6 +279,27 @@ class Context:
                                                _p(xy, _i32p), _p(sc, _f64p), _p(cnt, _i32p)))
         return [(xy[i, : cnt[i]].copy(), sc[i, : cnt[i]].copy()) for i in range(n)]
 
+    def detect_fast(self, slot, cells, max_per_cell, threshold=10, nonmax=True):
+        """cv::FAST per view (views may be as large as the frame): [(xy (k,2) int32, response (k,) float32)] per cell"""
+        cells = np.ascontiguousarray(cells, np.int32).reshape(-1, 4)
+        n = cells.shape[0]
+        cap = max(max_per_cell, 1)
+        xy = np.zeros((n, cap, 2), np.int32)
+        rs = np.zeros((n, cap), np.float32)
+        cnt = np.zeros(n, np.int32)
+        self._ck(self.lib.pmv_detect_fast(self.h, slot, _p(cells, _i32p), n, max_per_cell, threshold, 1 if nonmax else 0, _p(xy, _i32p), _p(rs, _f32p),
+                                          _p(cnt, _i32p)))
+        return [(xy[i, : cnt[i]].copy(), rs[i, : cnt[i]].copy()) for i in range(n)]
+
+    def knn_match(self, src_slot, cmp_slot, src_xy, cmp_xy, neighbours=7, window=15):
+        """kNNFeatureMatcher's arithmetic: (best candidate index or -1, window error) per source feature"""
+        s = np.ascontiguousarray(src_xy, np.int32).reshape(-1, 2)
+        c = np.ascontiguousarray(cmp_xy, np.int32).reshape(-1, 2)
+        best = np.zeros(max(len(s), 1), np.int32)
+        err = np.zeros(max(len(s), 1), np.float32)
+        self._ck(self.lib.pmv_knn_match(self.h, src_slot, cmp_slot, _p(s, _i32p), len(s), _p(c, _i32p), len(c), neighbours, window, _p(best, _i32p), _p(err, _f32p)))
+        return best[: len(s)].copy(), err[: len(s)].copy()
+
     def gftt_response(self, slot, cell):
         cell = np.ascontiguousarray(cell, np.int32)
         out = np.zeros((cell[3], cell[2]), np.float32)
@@ -416,12 +437,12 @@ class Context:
     # ---- whole sequence (OdometryPipeline role) ----
     def pipeline_run(self, n_frames, w, h, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5,
                      ba_iterations=5, extractor=0, threaded=0, build_pyramids=1, want_features=True, n_threads=1, async_free=False,
-                     defer_free=False, host_frames=None):
+                     defer_free=False, host_frames=None, matcher=0):
         """frames 0..n_frames-1 must be staged in slots 0..n_frames-1 (frames_stage) unless host_frames (n, h, w) uint8 is given:
         then they are streamed from host memory while the pipeline runs (pmv_pipeline_run_streamed). n_threads: host threads that
         evaluate the five-point RANSAC hypotheses of the triangulator side by side (the results do not depend on it)"""
         P = PipelineParams(n_frames, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
-                           n_threads, build_pyramids)
+                           n_threads, build_pyramids, matcher)
         Kd = np.ascontiguousarray(K, np.float64).reshape(9)
         gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n_frames, 12)
         out = C.c_void_p()
@@ -459,7 +480,7 @@ class Context:
         first = (C.c_int * B)()
         Kd = np.ascontiguousarray(np.broadcast_to(np.asarray(K, np.float64).reshape(-1, 9), (B, 9)))
         for b, (fs, n, gt) in enumerate(seqs):
-            params[b] = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded, 1, build_pyramids)
+            params[b] = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded, 1, build_pyramids, 0)
             g = np.ascontiguousarray(gt, np.float64).reshape(n, 12)
             gts.append(g)
             gt_ptrs[b] = _p(g, _f64p)

@@ -87,6 +87,8 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     CK(hipHostGetDevicePointer((void**)&c->dm_out_xy, c->h_out_xy, 0));
     CK(hipHostGetDevicePointer((void**)&c->dm_status, c->h_status, 0));
     CK(hipHostGetDevicePointer((void**)&c->dm_err, c->h_err, 0));
+    CK(hipMalloc(&c->d_knn, nt * 16 + 64));
+    CK(hipHostMalloc(&c->h_knn, nt * 16 + 64));
     CK(hipMalloc(&c->d_lk_counters, 32));
     CK(hipMemset(c->d_lk_counters, 0, 32));
     CK(hipMalloc(&c->d_cells, MAX_CELLS * CELL_STRIDE * 4));
@@ -126,6 +128,8 @@ void pmv_ctx_destroy(pmv_ctx* c) {
     c->prof.destroy();
     if (c->d_lk_stamps) hipFree(c->d_lk_stamps);
     if (c->d_lk_counters) hipFree(c->d_lk_counters);
+    if (c->d_knn) hipFree(c->d_knn);
+    if (c->h_knn) hipHostFree(c->h_knn);
     hipFree(c->d_slots); hipFree(c->d_prev_xy); hipFree(c->d_out_xy); hipFree(c->d_status); hipFree(c->d_err);
     hipHostFree(c->h_prev_xy); hipHostFree(c->h_out_xy); hipHostFree(c->h_status); hipHostFree(c->h_err);
     hipFree(c->d_cells); hipFree(c->d_eig); hipFree(c->d_cellmax); hipFree(c->d_det_xy); hipFree(c->d_det_score);

@@ -58,6 +58,31 @@ struct HipShiTomasi : ShiTomasiExtractorBase {
             }
     }
 };
+struct HipFast : FastExtractorBase {
+    pmv_ctx* ctx;
+    std::vector<int> rect, xy, cnt;
+    std::vector<float> rs;
+    void fast(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out,
+              std::vector<std::vector<float>>& response) override {
+        out.assign(cells.size(), {});
+        response.assign(cells.size(), {});
+        if (cells.empty() || max < 1) return;
+        cells_of(cells, rect);
+        xy.resize(cells.size() * (size_t)max * 2); rs.resize(cells.size() * (size_t)max); cnt.resize(cells.size());
+        ck(ctx, pmv_detect_fast(ctx, cells[0].slot, rect.data(), (int)cells.size(), max, threshold, nonmax ? 1 : 0, xy.data(), rs.data(), cnt.data()));
+        for (size_t c = 0; c < cells.size(); c++)
+            for (int i = 0; i < cnt[c]; i++) {
+                out[c].push_back({xy[(c * max + i) * 2], xy[(c * max + i) * 2 + 1]});
+                response[c].push_back(rs[c * max + i]);
+            }
+    }
+};
+struct HipKnn : KnnFeatureMatcherBase {
+    pmv_ctx* ctx;
+    void knn(const ImageView& src, const ImageView& next, const int* src_xy, int n, const int* cmp_xy, int m, int* best, float* err) override {
+        ck(ctx, pmv_knn_match(ctx, src.slot, next.slot, src_xy, n, cmp_xy, m, neighbours, window, best, err));
+    }
+};
 struct HipLK : LucasKanadeFMBase {
     pmv_ctx* ctx;
     void pyrlk(const ImageView& prev, const ImageView& next, const float* prev_xy, int n, float* next_xy, uint8_t* status,
@@ -201,15 +226,20 @@ int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K
     vp.n_frames = P->n_frames; vp.w = P->w; vp.h = P->h;
     vp.min_tracked_features = P->min_tracked_features; vp.tracked_features_tol = P->tracked_features_tol;
     vp.init_frames = P->init_frames; vp.bundle_size = P->bundle_size; vp.ba_iterations = P->ba_iterations;
-    vp.extractor = P->extractor; vp.threaded = P->threaded; vp.n_threads = P->n_threads; vp.reserved = 0;
+    vp.extractor = P->extractor; vp.threaded = P->threaded; vp.n_threads = P->n_threads; vp.reserved = 0; vp.matcher = P->matcher;
     try {
         if (P->build_pyramids) ck(ctx, pmv_frames_build(ctx, 0, P->n_frames));
         vo::pipeline_setup(run, vp, nullptr, K9, gt_poses12);
         vo::BaseFeatureExtractor* ex;
         if (P->extractor == 1) { auto* e = new HipShiTomasi(); e->ctx = ctx; ex = e; }
+        else if (P->extractor == 2) { auto* e = new HipFast(); e->ctx = ctx; ex = e; }
         else { auto* e = new HipGftt(); e->ctx = ctx; ex = e; }
         run.owned_ex.push_back(ex);
-        auto* lk = new HipLK(); lk->ctx = ctx;
+        vo::BaseFeatureMatcher* lk;
+        if (P->matcher == 1) {   // kNNFeatureMatcher(extractor): the reference's alternative matcher; it calls the extractor on whole frames
+            if (P->extractor != 2) throw std::runtime_error("the kNN matcher needs an extractor that accepts whole frames: extractor = 2 (FAST)");
+            auto* k = new HipKnn(); k->ctx = ctx; k->extractor = ex; lk = k;
+        } else { auto* l = new HipLK(); l->ctx = ctx; lk = l; }
         auto* pnp = new HipPnP(); pnp->ctx = ctx; pnp->tracker = &run.pipe;
         auto* tri = new HipTri(); tri->ctx = ctx; tri->tracker = &run.pipe; tri->workers = std::max(1, P->n_threads);
         auto* ba = new HipBA(); ba->ctx = ctx; ba->tracker = &run.pipe;
@@ -247,6 +277,7 @@ int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* param
         if (P.bundle_size != 0 && P.bundle_size < 3) { pmv::set_err(ctx, "pmv_pipeline_run_batch: bundle_size 1..2 divides by zero in the reference"); return PMV_ERR_INVALID; }
         if (P.bundle_size > ctx->max_ba_cams) { pmv::set_err(ctx, "pmv_pipeline_run_batch: bundle_size exceeds max_ba_cams"); return PMV_ERR_CAPACITY; }
         if (P.w != params[0].w || P.h != params[0].h) { pmv::set_err(ctx, "pmv_pipeline_run_batch: all sequences must share the frame size"); return PMV_ERR_INVALID; }
+        if (P.matcher != 0 || P.extractor > 1) { pmv::set_err(ctx, "pmv_pipeline_run_batch: the batch engine serves the reference's default plugins (LK; GFTT or ShiTomasi)"); return PMV_ERR_INVALID; }
     }
     pmv::BatchEngine* eng = nullptr;
     int rc = pmv::batch_engine_get(ctx, B, &eng);
@@ -267,7 +298,7 @@ int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* param
             vp.n_frames = P->n_frames; vp.w = P->w; vp.h = P->h;
             vp.min_tracked_features = P->min_tracked_features; vp.tracked_features_tol = P->tracked_features_tol;
             vp.init_frames = P->init_frames; vp.bundle_size = P->bundle_size; vp.ba_iterations = P->ba_iterations;
-            vp.extractor = P->extractor; vp.threaded = P->threaded; vp.n_threads = 1; vp.reserved = 0;
+            vp.extractor = P->extractor; vp.threaded = P->threaded; vp.n_threads = 1; vp.reserved = 0; vp.matcher = 0;
             try {
                 vo::pipeline_setup(run, vp, nullptr, K9 + 9 * b, gt_poses12[b]);
                 for (auto& im : run.pipe.images) im.slot += first_slot[b];

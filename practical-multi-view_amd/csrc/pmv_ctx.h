@@ -38,6 +38,7 @@ struct pmv_ctx {
     uint8_t* h_status = nullptr;
     float *dm_out_xy = nullptr, *dm_err = nullptr;   // device aliases of the mapped pinned result buffers
     uint8_t* dm_status = nullptr;
+    int *h_knn = nullptr, *d_knn = nullptr;      // kNN matcher coordinates: [src 2n | cmp 2m] ints, 2 * max_tracks pairs
     unsigned long long* d_lk_stamps = nullptr;   // diagnostic (PMV_LK_STAMPS=1)
     unsigned long long* d_lk_counters = nullptr; // 4 x u64 work counters (iterations, level passes, tracks), see pmv_lk_counters
     // detectors

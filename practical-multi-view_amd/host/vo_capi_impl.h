@@ -12,10 +12,11 @@ namespace vo {
 struct PipelineParams {          // plain C struct passed through ctypes
     int n_frames, w, h;
     int min_tracked_features, tracked_features_tol, init_frames, bundle_size, ba_iterations;
-    int extractor;               // 0 GFTT, 1 ShiTomasi
+    int extractor;               // 0 GFTT, 1 ShiTomasi, 2 FAST
     int threaded;                // 0 sequential schedule, 1 front-end/back-end threads
     int n_threads;               // CPU plugins only: worker threads for LK (the reference: OpenCV parallel_for_)
     int reserved;
+    int matcher;                 // 0 pyramidal LK, 1 kNN over `extractor`
 };
 
 struct PipelineRun {

@@ -76,6 +76,72 @@ std::vector<std::vector<Feature>> ShiTomasiExtractorBase::extractGrid(std::vecto
     return res;
 }
 
+// ---- OpenCVFASTFeatureExtractor.cpp:4-21 ---------------------------------------------------------------------------
+static std::vector<Feature> keypoints_to_features(const std::vector<std::pair<int, int>>& kp, const std::vector<float>& resp) {
+    std::vector<Feature> feats;
+    for (size_t i = 0; i < kp.size(); i++) {
+        Feature f(kp[i].first, kp[i].second);   // Feature(k.pt): column = x, row = y; tracked = true (:16), detector stays cv_good
+        f.score = resp[i];                      // k.response
+        f.tracked = true;
+        feats.push_back(f);
+    }
+    return feats;
+}
+std::vector<Feature> FastExtractorBase::extractFeatures(Frame& src, int max) {
+    std::vector<ImageView> cells{src.bw};
+    std::vector<std::vector<std::pair<int, int>>> out;
+    std::vector<std::vector<float>> resp;
+    fast(cells, max, out, resp);
+    return keypoints_to_features(out[0], resp[0]);
+}
+std::vector<std::vector<Feature>> FastExtractorBase::extractGrid(std::vector<Frame>& cells, int max) {
+    std::vector<ImageView> views;
+    for (auto& c : cells) views.push_back(c.bw);
+    std::vector<std::vector<std::pair<int, int>>> out;
+    std::vector<std::vector<float>> resp;
+    fast(views, max, out, resp);
+    std::vector<std::vector<Feature>> res;
+    for (size_t i = 0; i < out.size(); i++) res.push_back(keypoints_to_features(out[i], resp[i]));
+    return res;
+}
+
+// ---- kNNFeatureMatcher.cpp:3-61 --------------------------------------------------------------------------------------
+fmap KnnFeatureMatcherBase::matchFeatures(Frame& src, Frame& next) {
+    fmap map;
+    double avg = 0;
+    std::vector<std::shared_ptr<Feature>> new_feats, old_feats;
+    std::vector<bool> tracked;
+    std::vector<Feature> cmp_feats = extractor->extractFeatures(next, 1000);   // :11, on the whole next frame
+    for (auto& p : src.map) old_feats.push_back(p.first);
+    const int n = (int)old_feats.size(), m = (int)cmp_feats.size();
+    std::vector<int> src_xy(2 * (size_t)n), cmp_xy(2 * (size_t)m), best(n, -1);
+    std::vector<float> errs(n, 0.f);
+    for (int i = 0; i < n; i++) { src_xy[2 * i] = old_feats[i]->column; src_xy[2 * i + 1] = old_feats[i]->row; }
+    for (int j = 0; j < m; j++) { cmp_xy[2 * j] = cmp_feats[j].column; cmp_xy[2 * j + 1] = cmp_feats[j].row; }
+    if (n > 0) knn(src.bw, next.bw, src_xy.data(), n, cmp_xy.data(), m, best.data(), errs.data());   // :15-31 for every feature
+    for (int i = 0; i < n; i++) {
+        Feature best_fit = best[i] >= 0 ? cmp_feats[best[i]] : Feature();   // the neighbour copy (default-constructed when there was none)
+        const float err = errs[i];
+        if (err < threshold) {
+            tracked.push_back(true);
+            best_fit.tracked = true;
+            best_fit.displacement = old_feats[i]->distance(best_fit);
+            avg += best_fit.displacement;
+        } else
+            tracked.push_back(false);   // (the copy keeps the candidate's own `tracked` flag: quirk of the reference, :32-41)
+        new_feats.push_back(std::make_shared<Feature>(best_fit));
+    }
+    avg /= (double)new_feats.size();
+    for (auto& f : new_feats)
+        if (f->displacement > 3 * avg) f->tracked = false;
+    for (size_t i = 0; i < old_feats.size(); i++)
+        if (new_feats[i]->tracked) {
+            next.map[new_feats[i]] = src.map[old_feats[i]];
+            map[old_feats[i]] = new_feats[i];
+        }
+    return map;
+}
+
 // ---- OpenCVLucasKanadeFM.cpp:5-32 ----------------------------------------------------------------------------
 fmap LucasKanadeFMBase::matchFeatures(Frame& src, Frame& next) {
     fmap correspondences;

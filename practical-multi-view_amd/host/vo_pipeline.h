@@ -48,6 +48,25 @@ public:
     std::vector<Feature> extractFeatures(Frame& src, int max) override;
     std::vector<std::vector<Feature>> extractGrid(std::vector<Frame>& cells, int max) override;
 };
+class FastExtractorBase : public BaseFeatureExtractor {          // OpenCVFASTFeatureExtractor (threshold 10, nonmax: OpenCVFASTFeatureExtractor.h:11-12)
+public:
+    int threshold = 10;
+    bool nonmax = true;
+    // cv::FAST on each view; out[i] = the first `max` keypoints (x, y) of view i in cv::FAST's order, response[i] their KeyPoint::response
+    virtual void fast(const std::vector<ImageView>& cells, int max, std::vector<std::vector<std::pair<int, int>>>& out,
+                      std::vector<std::vector<float>>& response) = 0;
+    std::vector<Feature> extractFeatures(Frame& src, int max) override;
+    std::vector<std::vector<Feature>> extractGrid(std::vector<Frame>& cells, int max) override;
+};
+class KnnFeatureMatcherBase : public BaseFeatureMatcher {        // kNNFeatureMatcher (window 15, threshold 2, 7 neighbours: kNNFeatureMatcher.h:11-12,31)
+public:
+    int window = 15, threshold = 2, neighbours = 7;
+    BaseFeatureExtractor* extractor = nullptr;                   // kNNFeatureMatcher(BaseFeatureExtractor*): called on the whole next frame
+    // getNearestNeighbors + compareFeatures + best-fit rule for n source features against m candidates (pixel coordinates in the
+    // full images of src / next): best[i] = candidate index or -1 (the default Feature at (0,0)), err[i] = its window error
+    virtual void knn(const ImageView& src, const ImageView& next, const int* src_xy, int n, const int* cmp_xy, int m, int* best, float* err) = 0;
+    fmap matchFeatures(Frame& src, Frame& next) override;
+};
 class LucasKanadeFMBase : public BaseFeatureMatcher {            // OpenCVLucasKanadeFM (win 32, 4 levels)
 public:
     virtual void pyrlk(const ImageView& prev, const ImageView& next, const float* prev_xy, int n, float* next_xy,

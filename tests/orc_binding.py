@@ -70,6 +70,26 @@ class Oracle:
         self.lib.orc_pyr_down_fast(_p(img, _u8p), w, h, _p(out, _u8p))
         return out
 
+    def fast9_cell(self, img, cell, max_kp, threshold=10, nonmax=True):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        x0, y0, cw, ch = [int(v) for v in cell]
+        xy = np.zeros((max(max_kp, 1), 2), np.int32)
+        rs = np.zeros(max(max_kp, 1), np.float32)
+        n = self.lib.orc_fast9_cell(_p(img, _u8p), w, h, x0, y0, cw, ch, threshold, 1 if nonmax else 0, max_kp, _p(xy, _i32p), _p(rs, _f32p))
+        return xy[:n].copy(), rs[:n].copy()
+
+    def knn_match(self, src, cmp, src_xy, cmp_xy, neighbours=7, window=15):
+        src = np.ascontiguousarray(src, np.uint8)
+        cmp = np.ascontiguousarray(cmp, np.uint8)
+        h, w = src.shape
+        s = np.ascontiguousarray(src_xy, np.int32).reshape(-1, 2)
+        c = np.ascontiguousarray(cmp_xy, np.int32).reshape(-1, 2)
+        best = np.zeros(max(len(s), 1), np.int32)
+        err = np.zeros(max(len(s), 1), np.float32)
+        self.lib.orc_knn_match(_p(src, _u8p), _p(cmp, _u8p), w, h, _p(s, _i32p), len(s), _p(c, _i32p), len(c), neighbours, window, _p(best, _i32p), _p(err, _f32p))
+        return best[: len(s)].copy(), err[: len(s)].copy()
+
     def gftt_cell(self, img, cell, max_corners, quality=0.01, min_dist=5.0, want_eig=False):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
@@ -109,7 +129,7 @@ class PipelineParams(C.Structure):
     _fields_ = [("n_frames", C.c_int), ("w", C.c_int), ("h", C.c_int), ("min_tracked_features", C.c_int),
                 ("tracked_features_tol", C.c_int), ("init_frames", C.c_int), ("bundle_size", C.c_int),
                 ("ba_iterations", C.c_int), ("extractor", C.c_int), ("threaded", C.c_int), ("n_threads", C.c_int),
-                ("reserved", C.c_int)]
+                ("reserved", C.c_int), ("matcher", C.c_int)]
 
 
 class PipelineResult:
@@ -138,7 +158,7 @@ class PipelineResult:
 
 
 def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5, ba_iterations=5,
-                 extractor=0, threaded=0, n_threads=1, fast=False, lib=None):
+                 extractor=0, threaded=0, n_threads=1, fast=False, lib=None, matcher=0):
     """the oracle pipeline; fast=True: the speed-oriented twins (orc_fast.cpp; identical results), lib: another build of the
     same sources (bench.py times oracle/liborc_fast.so, built -O3 -march=native on the machine it runs on)"""
     o = load()
@@ -153,7 +173,7 @@ def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, b
     frames = np.ascontiguousarray(frames, np.uint8)
     n, h, w = frames.shape
     P = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
-                       n_threads, 1 if fast else 0)
+                       n_threads, 1 if fast else 0, matcher)
     Kd = np.ascontiguousarray(K, np.float64).reshape(9)
     gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n, 12)
     lib.orc_pipeline_run.argtypes = [C.POINTER(PipelineParams), _u8p, _f64p, _f64p]

