@@ -14,6 +14,7 @@
  *   pmv_knn_match                          kNNFeatureMatcher::matchFeatures' arithmetic   (kNNFeatureMatcher.cpp:13-31,63-122) -> BaseFeatureMatcher.h:22
  *   pmv_detect_fast                        cv::FAST                                      (OpenCVFASTFeatureExtractor.cpp:8) -> BaseFeatureExtractor.h:21
  *   pmv_pnp_ransac                         cv::solvePnPRansac                            (OpenCVEPnPSolver.cpp:35-36) -> BasePnPSolver.h:19
+ *   pmv_fivepoint_hypotheses               cv::findEssentialMat (RANSAC hypotheses)      (OpenCVFivePointTri.cpp:24) -> BaseTriangulator.h
  *   pmv_triangulate_candidates             cv::recoverPose (triangulation + cheirality)  (OpenCVFivePointTri.cpp:27) -> BaseTriangulator.h
  *   pmv_ba_residuals / pmv_ba_solve        ProjectionResidual + ceres::Solve             (ProjectionResidual.h:38-58,
  *                                          CeresBundleAdjustment.cpp:50-61)              -> BaseOptimizer.h:15
@@ -145,6 +146,16 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
                  const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations,
                  pmv_ba_summary* summary);
 
+/* ---- five-point RANSAC round -----------------------------------------------------------------------------
+ * The hypothesis half of cv::findEssentialMat(p1, p2, K, RANSAC, 0.99, 1.0) (OpenCVFivePointTri.cpp:24): for n_hyp (<= 64) samples of
+ * five correspondence indices each (the caller draws them from cv::RNG as RANSACPointSetRegistrator::getSubset does), Nister's
+ * solver gives up to 10 essential matrices per sample (models: n_hyp x 10 x 9 doubles, n_models: n_hyp) and every model is scored
+ * on all n normalised correspondences q1, q2 (x, y each) by the float32 Sampson distance <= thr (counts: n_hyp x 10). The caller
+ * replays the sequential bookkeeping (best so far, RANSACUpdateNumIters) in sample order. One thread per hypothesis: a latency
+ * chain, slower than a host core for one sequence, useful when many sequences' rounds share a launch (pmv_pipeline_run_batch). */
+int pmv_fivepoint_hypotheses(pmv_ctx* ctx, const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr, double* models,
+                             int* n_models, int* counts);
+
 /* ---- two-view triangulation ------------------------------------------------------------------ */
 /* The per-point part of cv::recoverPose(E, p1, p2, K, R, t, HUGE_VAL, mask, tri) (OpenCVFivePointTri.cpp:27): for each of
  * the four (R, t) candidates of decomposeEssentialMat, DLT-triangulate every correspondence (cv::triangulatePoints) and apply
@@ -194,6 +205,7 @@ typedef struct pmv_pipeline_params {
     int n_threads;      /* host threads that evaluate the triangulator's five-point RANSAC hypotheses side by side (>= 1; results do not depend on it) */
     int build_pyramids; /* rebuild the pyramids of slots 0..n_frames-1 inside the call */
     int matcher;        /* 0 = pyramidal LK (reference default), 1 = kNNFeatureMatcher over `extractor` */
+    int device_fivepoint; /* 0 = five-point RANSAC hypotheses on host threads, 1 = on the GPU (pmv_fivepoint_hypotheses); same results */
 } pmv_pipeline_params;
 typedef struct pmv_pipeline_result pmv_pipeline_result;
 

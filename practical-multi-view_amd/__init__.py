@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
     "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_detect_fast", "pmv_knn_match", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
-    "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates",
+    "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates", "pmv_fivepoint_hypotheses",
     "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
     "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_lk_counters", "pmv_prof_kernel_name", "pmv_prof_read",
     "pmv_pipeline_run", "pmv_pipeline_run_streamed", "pmv_pipeline_run_batch", "pmv_batch_stats", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
@@ -51,7 +51,7 @@ class PipelineParams(C.Structure):
     _fields_ = [("n_frames", C.c_int), ("w", C.c_int), ("h", C.c_int), ("min_tracked_features", C.c_int),
                 ("tracked_features_tol", C.c_int), ("init_frames", C.c_int), ("bundle_size", C.c_int),
                 ("ba_iterations", C.c_int), ("extractor", C.c_int), ("threaded", C.c_int), ("n_threads", C.c_int),
-                ("build_pyramids", C.c_int), ("matcher", C.c_int)]
+                ("build_pyramids", C.c_int), ("matcher", C.c_int), ("device_fivepoint", C.c_int)]
 
 
 STAT_KEYS = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
@@ -373,6 +373,19 @@ class Context:
                                        C.c_double(huber), max_iterations, C.byref(s)))
         return cams, pts, s
 
+    def fivepoint_hypotheses(self, q1, q2, samples, thr):
+        """one RANSAC round of findEssentialMat on the GPU: models (n_hyp, 10, 9), n_models (n_hyp,), counts (n_hyp, 10)"""
+        q1 = np.ascontiguousarray(q1, np.float64).reshape(-1, 2)
+        q2 = np.ascontiguousarray(q2, np.float64).reshape(-1, 2)
+        s = np.ascontiguousarray(samples, np.int32).reshape(-1, 5)
+        nh = s.shape[0]
+        models = np.zeros((nh, 10, 9), np.float64)
+        nm = np.zeros(nh, np.int32)
+        counts = np.zeros((nh, 10), np.int32)
+        self._ck(self.lib.pmv_fivepoint_hypotheses(self.h, _p(q1, _f64p), _p(q2, _f64p), q1.shape[0], _p(s, _i32p), nh, C.c_float(thr), _p(models, _f64p),
+                                                   _p(nm, _i32p), _p(counts, _i32p)))
+        return models, nm, counts
+
     def triangulate_candidates(self, q1, q2, P1x4, mask_in):
         """DLT triangulation + cheirality of cv::recoverPose's four candidates: returns Q (4,4,n), mask (4,n), good (4,)"""
         q1 = np.ascontiguousarray(q1, np.float64).reshape(-1, 2)
@@ -437,12 +450,12 @@ class Context:
     # ---- whole sequence (OdometryPipeline role) ----
     def pipeline_run(self, n_frames, w, h, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5,
                      ba_iterations=5, extractor=0, threaded=0, build_pyramids=1, want_features=True, n_threads=1, async_free=False,
-                     defer_free=False, host_frames=None, matcher=0):
+                     defer_free=False, host_frames=None, matcher=0, device_fivepoint=0):
         """frames 0..n_frames-1 must be staged in slots 0..n_frames-1 (frames_stage) unless host_frames (n, h, w) uint8 is given:
         then they are streamed from host memory while the pipeline runs (pmv_pipeline_run_streamed). n_threads: host threads that
         evaluate the five-point RANSAC hypotheses of the triangulator side by side (the results do not depend on it)"""
         P = PipelineParams(n_frames, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded,
-                           n_threads, build_pyramids, matcher)
+                           n_threads, build_pyramids, matcher, device_fivepoint)
         Kd = np.ascontiguousarray(K, np.float64).reshape(9)
         gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n_frames, 12)
         out = C.c_void_p()
@@ -469,7 +482,7 @@ class Context:
         return r
 
     def pipeline_run_batch(self, seqs, w, h, K, min_tracked=400, tol=150, init_frames=5, bundle_size=5, ba_iterations=5, extractor=0,
-                           build_pyramids=1, want_features=True, defer_free=False, threaded=1):
+                           build_pyramids=1, want_features=True, defer_free=False, threaded=1, device_fivepoint=0):
         """B independent sequences through batched launches (pmv_pipeline_run_batch). seqs: list of (first_slot, n_frames, gt_poses);
         the frames must be staged in slots first_slot..first_slot+n_frames-1. K: 9 values shared by all, or (B, 9). Returns one
         PipelineResult per sequence (bit-identical to pipeline_run on the same sequence)."""
@@ -480,7 +493,7 @@ class Context:
         first = (C.c_int * B)()
         Kd = np.ascontiguousarray(np.broadcast_to(np.asarray(K, np.float64).reshape(-1, 9), (B, 9)))
         for b, (fs, n, gt) in enumerate(seqs):
-            params[b] = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded, 1, build_pyramids, 0)
+            params[b] = PipelineParams(n, w, h, min_tracked, tol, init_frames, bundle_size, ba_iterations, extractor, threaded, 1, build_pyramids, 0, device_fivepoint)
             g = np.ascontiguousarray(gt, np.float64).reshape(n, 12)
             gts.append(g)
             gt_ptrs[b] = _p(g, _f64p)

@@ -24,6 +24,7 @@ struct BackendBuffers {
     void* d_bastate = nullptr;
     double* d_bapart = nullptr;
     char *d_tri_in = nullptr, *d_tri_out = nullptr;
+    char* d_fp_work = nullptr;   // five-point round: [models FP_MAX_HYP x 90 doubles | n_models FP_MAX_HYP ints] (inputs share d_tri_in)
     char* d_h_stage = nullptr;   // device address of the pinned staging block: result blocks are written straight into it
     size_t tri_in_bytes = 0, tri_out_bytes = 0;
     // single-copy transfers: one pinned staging block and one device block per direction
@@ -88,6 +89,15 @@ struct PnPProblem {
     int m, n_hyp; float thr; double confidence;
 };
 hipError_t launch_pnp_batch(hipStream_t s, const PnPProblem* d_probs, int n_probs, int max_hyp);
+// one findEssentialMat RANSAC round of a batched five-point launch (backend_fivepoint.hip): n_hyp samples of 5 correspondences each
+struct FivePointProblem {
+    const int* samples; const double* q1; const double* q2;   // device inputs: 5 n_hyp indices, n normalised points each
+    double* models_d; int* n_models_d;                        // device: n_hyp x 90 doubles, n_hyp ints (read by the scoring kernel)
+    double* models_h; int* n_models_h; int* counts_h;         // mapped pinned results: models, model counts, n_hyp x 10 inlier counts
+    int n, n_hyp; float thr;
+};
+constexpr int FP_MAX_HYP = 64;   // hypotheses per round
+hipError_t launch_fivepoint_batch(hipStream_t s, const FivePointProblem* d_probs, int n_probs, int max_hyp);
 // one two-view problem of a batched DLT launch
 struct DltProblem { const double* P1x4; const double* q1; const double* q2; const uint8_t* mask_in; double* Q; uint8_t* mask; int n; };
 hipError_t launch_tri_dlt_batch(hipStream_t s, const DltProblem* d_probs, int n_probs, int max_n);
@@ -113,6 +123,10 @@ int ba_prepare(pmv_ctx* ctx, BackendBuffers* b, const double* cams, int nc, cons
                const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations, bool multi, BAArgs* A, size_t* io_bytes);
 void ba_finish(pmv_ctx* ctx, BackendBuffers* b, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
                const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations, pmv_ba_summary* summary);
+// five-point round: samples (5 n_hyp ints) of n normalised correspondences; thr = squared Sampson threshold as float
+int fivepoint_prepare(pmv_ctx* ctx, BackendBuffers* b, const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr,
+                      FivePointProblem* P, size_t* in_bytes);
+void fivepoint_finish(BackendBuffers* b, int n_hyp, size_t in_bytes, double* models, int* n_models, int* counts);
 void dlt_prepare(BackendBuffers* b, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, DltProblem* P,
                  size_t* in_bytes);
 void dlt_finish(pmv_ctx* ctx, BackendBuffers* b, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,

@@ -55,8 +55,10 @@ int backend_alloc(pmv_ctx* c, BackendBuffers** out) {
     b->tri_out_bytes = mt * 16 * 8 + mt * 4 + 64;
     CKB(hipMalloc(&b->d_tri_in, b->tri_in_bytes));
     CKB(hipMalloc(&b->d_tri_out, b->tri_out_bytes));
+    CKB(hipMalloc(&b->d_fp_work, (size_t)FP_MAX_HYP * (90 * 8 + 4) + 64));
     b->h_stage_bytes = std::max(b->h_stage_bytes, std::max(b->ba_io_bytes, b->pnp_in_bytes + b->pnp_out_bytes));
     b->h_stage_bytes = std::max(b->h_stage_bytes, b->tri_in_bytes + b->tri_out_bytes);
+    b->h_stage_bytes = std::max(b->h_stage_bytes, b->tri_in_bytes + (size_t)FP_MAX_HYP * (90 * 8 + 44) + 256);   // five-point round in + out
     (void)hipHostFree(b->h_stage);
     CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes, hipHostMallocMapped));
     CKB(hipHostGetDevicePointer((void**)&b->d_h_stage, b->h_stage, 0));
@@ -78,7 +80,8 @@ void backend_free(BackendBuffers* b) {
     void* ptrs[] = {b->d_cams, b->d_pts, b->d_obs, b->d_K, b->d_cam_idx, b->d_pt_idx, b->d_pobs_start, b->d_pobs_list, b->d_cobs_start,
                     b->d_cobs_list, b->d_x, b->d_cand, b->d_scale, b->d_diag, b->d_D2, b->d_step, b->d_res, b->d_J, b->d_Einv, b->d_gp,
                     b->d_Yd, b->d_Wd, b->d_S, b->d_rhs, b->d_Gpart, b->d_summary, b->d_obj, b->d_img, b->d_samples, b->d_counts,
-                    b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out, b->d_bastate, b->d_bapart, b->d_tri_in, b->d_tri_out};
+                    b->d_inliers, b->d_info, b->d_models, b->d_rt, b->d_Kp, b->d_masks, b->d_ba_io, b->d_pnp_in, b->d_pnp_out, b->d_bastate, b->d_bapart, b->d_tri_in, b->d_tri_out,
+                    b->d_fp_work};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (b->d_stamps) (void)hipFree(b->d_stamps);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
@@ -461,6 +464,42 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
 
 }  // extern "C"
 
+// ---- five-point RANSAC round: prepare / finish ----------------------------------------------------------------------------------
+int pmv::fivepoint_prepare(pmv_ctx* ctx, BackendBuffers* b, const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr,
+                           FivePointProblem* P, size_t* in_bytes_out) {
+    REQ(q1 && q2 && samples && n >= 5 && n <= ctx->max_tracks && n_hyp >= 1 && n_hyp <= FP_MAX_HYP, PMV_ERR_INVALID,
+        "five-point round: n=%d (5..max_tracks=%d), n_hyp=%d (1..%d)", n, ctx->max_tracks, n_hyp, FP_MAX_HYP);
+    char* hs = (char*)b->h_stage;
+    // pinned in-block [q1 2n | q2 2n doubles | samples 5 n_hyp ints], out-block [models 90 n_hyp doubles | n_models n_hyp | counts 10 n_hyp ints]
+    double* h_q1 = (double*)hs;
+    double* h_q2 = h_q1 + (size_t)2 * n;
+    int* h_s = (int*)(h_q2 + (size_t)2 * n);
+    const size_t in_bytes = (size_t)4 * n * 8 + (size_t)5 * n_hyp * 4;
+    REQ(in_bytes <= b->tri_in_bytes, PMV_ERR_CAPACITY, "five-point round: input block too small");
+    memcpy(h_q1, q1, (size_t)n * 16); memcpy(h_q2, q2, (size_t)n * 16); memcpy(h_s, samples, (size_t)5 * n_hyp * 4);
+    P->q1 = (const double*)b->d_tri_in;
+    P->q2 = P->q1 + (size_t)2 * n;
+    P->samples = (const int*)(P->q2 + (size_t)2 * n);
+    P->models_d = (double*)b->d_fp_work;
+    P->n_models_d = (int*)(b->d_fp_work + (size_t)FP_MAX_HYP * 90 * 8);
+    char* ho = hs + ((in_bytes + 63) & ~(size_t)63);
+    char* dho = b->d_h_stage + (ho - hs);
+    P->models_h = (double*)dho;
+    P->n_models_h = (int*)(dho + (size_t)n_hyp * 90 * 8);
+    P->counts_h = P->n_models_h + n_hyp;
+    P->n = n; P->n_hyp = n_hyp; P->thr = thr;
+    // hypotheses whose sample is degenerate write no models: clear the counts the host will read
+    memset(ho + (size_t)n_hyp * 90 * 8, 0, (size_t)n_hyp * 44);
+    *in_bytes_out = in_bytes;
+    return PMV_OK;
+}
+void pmv::fivepoint_finish(BackendBuffers* b, int n_hyp, size_t in_bytes, double* models, int* n_models, int* counts) {
+    const char* ho = (const char*)b->h_stage + ((in_bytes + 63) & ~(size_t)63);
+    memcpy(models, ho, (size_t)n_hyp * 90 * 8);
+    memcpy(n_models, ho + (size_t)n_hyp * 90 * 8, (size_t)n_hyp * 4);
+    memcpy(counts, ho + (size_t)n_hyp * 90 * 8 + (size_t)n_hyp * 4, (size_t)n_hyp * 40);
+}
+
 // ---- two-view DLT: prepare / finish -------------------------------------------------------------------------------------------
 void pmv::dlt_prepare(BackendBuffers* b, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, DltProblem* P,
                       size_t* in_bytes_out) {
@@ -504,6 +543,26 @@ void pmv::dlt_finish(pmv_ctx* ctx, BackendBuffers* b, const double* q1, const do
 }
 
 extern "C" {
+
+// one round of cv::findEssentialMat's RANSAC (OpenCVFivePointTri.cpp:24) on the device: see include/pmv_hip.h
+int pmv_fivepoint_hypotheses(pmv_ctx* ctx, const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr, double* models,
+                             int* n_models, int* counts) {
+    REQ(ctx && models && n_models && counts, PMV_ERR_INVALID, "pmv_fivepoint_hypotheses: null argument");
+    tl_prof = &ctx->prof;
+    CKC(hipSetDevice(ctx->device));
+    BackendBuffers* b = ctx->be;
+    hipStream_t s = ctx->s_back;
+    FivePointProblem P;
+    size_t in_bytes = 0;
+    int rc = fivepoint_prepare(ctx, b, q1, q2, n, samples, n_hyp, thr, &P, &in_bytes);
+    if (rc) return rc;
+    CKC(hipMemcpyAsync(b->d_tri_in, b->h_stage, in_bytes, hipMemcpyHostToDevice, s));
+    CKC(hipMemcpyAsync(b->d_tri_out, &P, sizeof(P), hipMemcpyHostToDevice, s));   // the problem record (d_tri_out is free during a five-point round)
+    CKC(launch_fivepoint_batch(s, (const FivePointProblem*)b->d_tri_out, 1, n_hyp));
+    CKC(hipStreamSynchronize(s));
+    fivepoint_finish(b, n_hyp, in_bytes, models, n_models, counts);
+    return PMV_OK;
+}
 
 // the per-point part of cv::recoverPose (OpenCVFivePointTri.cpp:27): DLT triangulation + cheirality for the four candidates
 int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,

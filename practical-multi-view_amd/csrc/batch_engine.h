@@ -20,4 +20,6 @@ int engine_ba(BatchEngine* E, int seq, double* cams, int nc, double* pts, int np
               const double* K, double huber, int max_iterations);
 int engine_dlt(BatchEngine* E, int seq, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
                uint8_t* out_mask, int* out_good);
+int engine_fivepoint(BatchEngine* E, int seq, const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr, double* models,
+                     int* n_models, int* counts);
 }  // namespace pmv

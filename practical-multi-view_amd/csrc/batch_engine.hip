@@ -50,6 +50,7 @@ struct DetReq : Req {
 struct PnPReq : Req { BackendBuffers* b; PnPProblem P; size_t in_bytes; };
 struct BAReq : Req { BackendBuffers* b; BAArgs A; size_t io_bytes; int max_iterations; };
 struct DltReq : Req { BackendBuffers* b; DltProblem P; size_t in_bytes; };
+struct FPReq : Req { BackendBuffers* b; FivePointProblem P; size_t in_bytes; };
 
 struct Growable {   // device (or pinned host) buffer that only grows
     void* p = nullptr; size_t cap = 0; bool host = false;
@@ -64,19 +65,29 @@ struct Growable {   // device (or pinned host) buffer that only grows
     void release() { if (p) { (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; cap = 0; } }
 };
 
-enum Role { R_LK = 0, R_DET, R_PNP, R_BA, R_DLT, R_COUNT };
-struct Combiner {
+enum Role { R_LK = 0, R_DET, R_PNP, R_BA, R_DLT, R_FP, R_COUNT };
+struct Queue {   // pending requests of one kernel class
     std::mutex mu;
     std::condition_variable cv_new;
     std::vector<Req*> pending;
     bool stop = false;
+};
+constexpr int MAX_LANES = 4;
+// One combiner = one thread + one HIP stream + its staging buffers. A class may have several (PMV_BATCH_LANES, default 1): while
+// one waits for its launch, the next takes the requests that have arrived meanwhile instead of letting them sit for a whole round.
+struct Combiner {
     std::thread th;
-    hipStream_t s = nullptr;           // this class's own stream
+    hipStream_t s = nullptr;           // this combiner's own stream
     hipEvent_t ev = nullptr;           // blocking-sync event for the interrupt-driven wait
     Growable h_desc{nullptr, 0, true}, d_desc;   // per-batch descriptors (+ stage-in jobs), pinned mirror and device copy
     long batches = 0, requests = 0;
     double t_idle = 0, t_work = 0, t_sync = 0;   // seconds: waiting for requests / processing a batch / inside hipStreamSynchronize
     double t_cpu = 0;                            // CPU seconds of the combiner thread itself
+    // LK staging + mapped pinned result blocks; detector buffers (only used by combiners of those classes)
+    Growable h_front{nullptr, 0, true}, d_front, h_cells{nullptr, 0, true}, d_cells, d_eig, d_cellmax, d_det_xy, d_det_score, d_det_count, h_det{nullptr, 0, true};
+    float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr;
+    float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr;
+    int* d_flags = nullptr;
 };
 
 // one input block to pull from mapped pinned host memory into HBM (16-byte granules; both buffers have >= 16 B of slack)
@@ -97,13 +108,10 @@ struct BatchEngine {
     int linger_us = 0;
     int wait_mode = 2;   // 0 spin (hipStreamSynchronize), 1 query + yield, 2 blocking event
     std::vector<BackendBuffers*> slots;   // one back-end workspace set per concurrent sequence
-    Combiner comb[R_COUNT];
-    // front staging
-    Growable h_front{nullptr, 0, true}, d_front, h_cells{nullptr, 0, true}, d_cells, d_eig, d_cellmax, d_det_xy, d_det_score, d_det_count, h_det{nullptr, 0, true};
-    float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr;    // mapped pinned LK results
-    float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr;
+    int lanes = 1;   // measured: 2 and 3 combiners per class cost more host CPU (smaller batches) than they win in latency: 25.7k -> 23.3k -> 19.5k frames/s at B = 64
+    Queue queue[R_COUNT];
+    Combiner comb[R_COUNT][MAX_LANES];
     size_t cap_tracks = 0;
-    int* d_flags = nullptr;
 };
 
 namespace {
@@ -158,8 +166,8 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
         const size_t off_blocks = (sizeof(LKSeq) * lk.size() + 63) & ~(size_t)63;
         const size_t off_xy = (off_blocks + sizeof(int2) * (size_t)total_blocks + 63) & ~(size_t)63;
         const size_t bytes = off_xy + (size_t)total_tracks * 8;
-        EK(E->h_front.ensure(bytes)); EK(E->d_front.ensure(bytes));
-        char* hb = (char*)E->h_front.p;
+        EK(C.h_front.ensure(bytes)); EK(C.d_front.ensure(bytes));
+        char* hb = (char*)C.h_front.p;
         LKSeq* hseq = (LKSeq*)hb;
         int2* hblk = (int2*)(hb + off_blocks);
         float* hxy = (float*)(hb + off_xy);
@@ -172,19 +180,19 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
             memcpy(hxy + (size_t)2 * r->base, r->prev_xy, (size_t)r->n * 8);
             q++;
         }
-        EK(hipMemcpyAsync(E->d_front.p, hb, bytes, hipMemcpyHostToDevice, s));
+        EK(hipMemcpyAsync(C.d_front.p, hb, bytes, hipMemcpyHostToDevice, s));
         LKParams P;
         P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f; P.stamps = nullptr; P.counters = ctx->d_lk_counters;
-        char* db = (char*)E->d_front.p;
+        char* db = (char*)C.d_front.p;
         EK(launch_lk_batch(s, ctx->d_slots, (const LKSeq*)db, (const int2*)(db + off_blocks), total_blocks, L, (const float*)(db + off_xy), P,
-                           E->dm_out_xy, E->dm_status, E->dm_err));
+                           C.dm_out_xy, C.dm_status, C.dm_err));
     }
     SYNC_TIMED(C);
     for (LKReq* r : lk) {
         if (r->rc != PMV_OK) continue;
-        memcpy(r->out_xy, E->h_out_xy + (size_t)2 * r->base, (size_t)r->n * 8);
-        memcpy(r->status, E->h_status + r->base, (size_t)r->n);
-        memcpy(r->err_out, E->h_err + r->base, (size_t)r->n * 4);
+        memcpy(r->out_xy, C.h_out_xy + (size_t)2 * r->base, (size_t)r->n * 8);
+        memcpy(r->status, C.h_status + r->base, (size_t)r->n);
+        memcpy(r->err_out, C.h_err + r->base, (size_t)r->n * 4);
     }
 }
 
@@ -210,11 +218,11 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     {
         size_t tot_cells = 0, tot_out = 0;
         for (Group& g : groups) { g.out_off = tot_out; tot_cells += g.n_cells; tot_out += (size_t)g.n_cells * g.max_per_cell; }
-        EK(E->h_cells.ensure(tot_cells * CELL_STRIDE * 4)); EK(E->d_cells.ensure(tot_cells * CELL_STRIDE * 4));
-        EK(E->d_eig.ensure(tot_cells * CELL_PIX * sizeof(double))); EK(E->d_cellmax.ensure(tot_cells * 8));
-        EK(E->d_det_xy.ensure(tot_out * 8)); EK(E->d_det_score.ensure(tot_out * 8)); EK(E->d_det_count.ensure(tot_cells * 4));
-        EK(E->h_det.ensure(tot_out * 16 + tot_cells * 4 + 64));
-        int* hc = (int*)E->h_cells.p;
+        EK(C.h_cells.ensure(tot_cells * CELL_STRIDE * 4)); EK(C.d_cells.ensure(tot_cells * CELL_STRIDE * 4));
+        EK(C.d_eig.ensure(tot_cells * CELL_PIX * sizeof(double))); EK(C.d_cellmax.ensure(tot_cells * 8));
+        EK(C.d_det_xy.ensure(tot_out * 8)); EK(C.d_det_score.ensure(tot_out * 8)); EK(C.d_det_count.ensure(tot_cells * 4));
+        EK(C.h_det.ensure(tot_out * 16 + tot_cells * 4 + 64));
+        int* hc = (int*)C.h_cells.p;
         size_t cpos = 0;
         for (Group& g : groups)
             for (DetReq* r : g.reqs)
@@ -222,33 +230,33 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
                     int* d = hc + cpos * CELL_STRIDE;
                     d[0] = r->cells[4 * i]; d[1] = r->cells[4 * i + 1]; d[2] = r->cells[4 * i + 2]; d[3] = r->cells[4 * i + 3]; d[4] = r->slot; d[5] = d[6] = d[7] = 0;
                 }
-        EK(hipMemcpyAsync(E->d_cells.p, hc, tot_cells * CELL_STRIDE * 4, hipMemcpyHostToDevice, s));
-        EK(hipMemsetAsync(E->d_flags, 0, 16, s));
+        EK(hipMemcpyAsync(C.d_cells.p, hc, tot_cells * CELL_STRIDE * 4, hipMemcpyHostToDevice, s));
+        EK(hipMemsetAsync(C.d_flags, 0, 16, s));
         size_t c0 = 0;
-        char* hd = (char*)E->h_det.p;
+        char* hd = (char*)C.h_det.p;
         for (Group& g : groups) {
-            const int* dc = (const int*)E->d_cells.p + c0 * CELL_STRIDE;
-            int* dxy = (int*)E->d_det_xy.p + g.out_off * 2;
-            double* dsc = (double*)E->d_det_score.p + g.out_off;
-            int* dcnt = (int*)E->d_det_count.p + c0;
+            const int* dc = (const int*)C.d_cells.p + c0 * CELL_STRIDE;
+            int* dxy = (int*)C.d_det_xy.p + g.out_off * 2;
+            double* dsc = (double*)C.d_det_score.p + g.out_off;
+            int* dcnt = (int*)C.d_det_count.p + c0;
             if (g.kind == 1)
-                EK(launch_gftt(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, g.min_dist, g.unlimited, (float*)E->d_eig.p + c0 * CELL_PIX,
-                               (unsigned*)E->d_cellmax.p + c0, dxy, dcnt, E->d_flags));
+                EK(launch_gftt(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, g.min_dist, g.unlimited, (float*)C.d_eig.p + c0 * CELL_PIX,
+                               (unsigned*)C.d_cellmax.p + c0, dxy, dcnt, C.d_flags));
             else
-                EK(launch_shitomasi(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, (double*)E->d_eig.p + c0 * CELL_PIX,
-                                    (unsigned long long*)E->d_cellmax.p + c0, dxy, dsc, dcnt, E->d_flags));
+                EK(launch_shitomasi(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, (double*)C.d_eig.p + c0 * CELL_PIX,
+                                    (unsigned long long*)C.d_cellmax.p + c0, dxy, dsc, dcnt, C.d_flags));
             c0 += g.n_cells;
         }
-        EK(hipMemcpyAsync(hd, E->d_det_xy.p, tot_out * 8, hipMemcpyDeviceToHost, s));
-        EK(hipMemcpyAsync(hd + tot_out * 8, E->d_det_score.p, tot_out * 8, hipMemcpyDeviceToHost, s));
-        EK(hipMemcpyAsync(hd + tot_out * 16, E->d_det_count.p, tot_cells * 4, hipMemcpyDeviceToHost, s));
-        EK(hipMemcpyAsync(hd + tot_out * 16 + tot_cells * 4, E->d_flags, 4, hipMemcpyDeviceToHost, s));
+        EK(hipMemcpyAsync(hd, C.d_det_xy.p, tot_out * 8, hipMemcpyDeviceToHost, s));
+        EK(hipMemcpyAsync(hd + tot_out * 8, C.d_det_score.p, tot_out * 8, hipMemcpyDeviceToHost, s));
+        EK(hipMemcpyAsync(hd + tot_out * 16, C.d_det_count.p, tot_cells * 4, hipMemcpyDeviceToHost, s));
+        EK(hipMemcpyAsync(hd + tot_out * 16 + tot_cells * 4, C.d_flags, 4, hipMemcpyDeviceToHost, s));
     }
     SYNC_TIMED(C);
     {
         size_t tot_cells = 0, tot_out = 0;
         for (Group& g : groups) { tot_cells += g.n_cells; tot_out += (size_t)g.n_cells * g.max_per_cell; }
-        const char* hd = (const char*)E->h_det.p;
+        const char* hd = (const char*)C.h_det.p;
         const int flags = *(const int*)(hd + tot_out * 16 + tot_cells * 4);
         const int* hxy = (const int*)hd;
         const double* hsc = (const double*)(hd + tot_out * 8);
@@ -352,23 +360,39 @@ void process_dlt(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     SYNC_TIMED(C);
 }
 
-void combiner_loop(BatchEngine* E, int role) {
-    Combiner* C = &E->comb[role];
+void process_fp(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
+    DescBlock<FivePointProblem> D;
+    EK(desc_block(C, batch.size(), D));
+    int max_hyp = 0;
+    for (size_t i = 0; i < batch.size(); i++) {
+        FPReq* r = (FPReq*)batch[i];
+        D.hprob[i] = r->P;
+        D.hjobs[i] = StageJob{(const char*)r->b->d_h_stage, r->b->d_tri_in, (unsigned)r->in_bytes, 0};
+        max_hyp = std::max(max_hyp, r->P.n_hyp);
+    }
+    EK(stage_in(C, D, batch.size(), 2));
+    EK(launch_fivepoint_batch(C.s, D.dprob, (int)batch.size(), max_hyp));
+    SYNC_TIMED(C);
+}
+
+void combiner_loop(BatchEngine* E, int role, int lane) {
+    Combiner* C = &E->comb[role][lane];
+    Queue* Q = &E->queue[role];
     (void)hipSetDevice(E->ctx->device);
     tl_prof = &E->ctx->prof;
     for (;;) {
         std::vector<Req*> batch;
         const auto ti = std::chrono::steady_clock::now();
         {
-            std::unique_lock<std::mutex> lk(C->mu);
-            C->cv_new.wait(lk, [&] { return !C->pending.empty() || C->stop; });
-            if (C->pending.empty() && C->stop) return;
-            if (E->linger_us > 0 && (int)C->pending.size() < E->B) {   // optional: give stragglers a moment to join the batch
+            std::unique_lock<std::mutex> lk(Q->mu);
+            Q->cv_new.wait(lk, [&] { return !Q->pending.empty() || Q->stop; });
+            if (Q->pending.empty() && Q->stop) return;
+            if (E->linger_us > 0 && (int)Q->pending.size() < E->B) {   // optional: give stragglers a moment to join the batch
                 lk.unlock();
                 std::this_thread::sleep_for(std::chrono::microseconds(E->linger_us));
                 lk.lock();
             }
-            batch.swap(C->pending);
+            batch.swap(Q->pending);
         }
         const auto tw = std::chrono::steady_clock::now();
         C->t_idle += std::chrono::duration<double>(tw - ti).count();
@@ -377,10 +401,11 @@ void combiner_loop(BatchEngine* E, int role) {
         case R_DET: process_det(E, *C, batch); break;
         case R_PNP: process_pnp(E, *C, batch); break;
         case R_BA: process_ba(E, *C, batch); break;
-        default: process_dlt(E, *C, batch); break;
+        case R_DLT: process_dlt(E, *C, batch); break;
+        default: process_fp(E, *C, batch); break;
         }
         {
-            std::lock_guard<std::mutex> lk(C->mu);
+            std::lock_guard<std::mutex> lk(Q->mu);
             C->batches++; C->requests += (long)batch.size();
             for (Req* r : batch) { r->done = true; r->cv.notify_one(); }   // after this the owner may destroy the request
         }
@@ -389,11 +414,11 @@ void combiner_loop(BatchEngine* E, int role) {
     }
 }
 
-int submit(pmv_ctx* ctx, Combiner& C, Req* r) {
+int submit(pmv_ctx* ctx, Queue& Q, Req* r) {
     {
-        std::unique_lock<std::mutex> lk(C.mu);
-        C.pending.push_back(r);
-        C.cv_new.notify_one();
+        std::unique_lock<std::mutex> lk(Q.mu);
+        Q.pending.push_back(r);
+        Q.cv_new.notify_one();
         r->cv.wait(lk, [&] { return r->done; });
     }
     if (r->rc != PMV_OK) set_err(ctx, "%s", r->err);
@@ -408,20 +433,22 @@ int submit(pmv_ctx* ctx, Combiner& C, Req* r) {
 void batch_engine_destroy(pmv_ctx* ctx) {
     BatchEngine* E = ctx->engine;
     if (!E) return;
-    for (Combiner& C : E->comb) {
-        { std::lock_guard<std::mutex> lk(C.mu); C.stop = true; }
-        C.cv_new.notify_all();
-        if (C.th.joinable()) C.th.join();
-        if (C.s) { (void)hipStreamSynchronize(C.s); (void)hipStreamDestroy(C.s); }
-        if (C.ev) (void)hipEventDestroy(C.ev);
-        C.h_desc.release(); C.d_desc.release();
+    for (Queue& Q : E->queue) {
+        { std::lock_guard<std::mutex> lk(Q.mu); Q.stop = true; }
+        Q.cv_new.notify_all();
     }
+    for (auto& role : E->comb)
+        for (Combiner& C : role) {
+            if (C.th.joinable()) C.th.join();
+            if (C.s) { (void)hipStreamSynchronize(C.s); (void)hipStreamDestroy(C.s); }
+            if (C.ev) (void)hipEventDestroy(C.ev);
+            for (Growable* g : {&C.h_desc, &C.d_desc, &C.h_front, &C.d_front, &C.h_cells, &C.d_cells, &C.d_eig, &C.d_cellmax, &C.d_det_xy, &C.d_det_score, &C.d_det_count, &C.h_det}) g->release();
+            if (C.h_out_xy) (void)hipHostFree(C.h_out_xy);
+            if (C.h_err) (void)hipHostFree(C.h_err);
+            if (C.h_status) (void)hipHostFree(C.h_status);
+            if (C.d_flags) (void)hipFree(C.d_flags);
+        }
     for (BackendBuffers* b : E->slots) backend_free(b);
-    for (Growable* g : {&E->h_front, &E->d_front, &E->h_cells, &E->d_cells, &E->d_eig, &E->d_cellmax, &E->d_det_xy, &E->d_det_score, &E->d_det_count, &E->h_det}) g->release();
-    if (E->h_out_xy) (void)hipHostFree(E->h_out_xy);
-    if (E->h_err) (void)hipHostFree(E->h_err);
-    if (E->h_status) (void)hipHostFree(E->h_status);
-    if (E->d_flags) (void)hipFree(E->d_flags);
     delete E;
     ctx->engine = nullptr;
 }
@@ -442,27 +469,39 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
         if (rc != PMV_OK) { batch_engine_destroy(ctx); return rc; }
     }
     E->cap_tracks = (size_t)B * ctx->max_tracks;
-    CKC(hipHostMalloc(&E->h_out_xy, E->cap_tracks * 8, hipHostMallocMapped));
-    CKC(hipHostMalloc(&E->h_status, E->cap_tracks, hipHostMallocMapped));
-    CKC(hipHostMalloc(&E->h_err, E->cap_tracks * 4, hipHostMallocMapped));
-    CKC(hipHostGetDevicePointer((void**)&E->dm_out_xy, E->h_out_xy, 0));
-    CKC(hipHostGetDevicePointer((void**)&E->dm_status, E->h_status, 0));
-    CKC(hipHostGetDevicePointer((void**)&E->dm_err, E->h_err, 0));
-    CKC(hipMalloc(&E->d_flags, 16));
-    for (int r = 0; r < R_COUNT; r++) {
-        CKC(hipStreamCreateWithFlags(&E->comb[r].s, hipStreamNonBlocking));
-        CKC(hipEventCreateWithFlags(&E->comb[r].ev, hipEventBlockingSync | hipEventDisableTiming));
-    }
+    if (const char* e = getenv("PMV_BATCH_LANES")) E->lanes = std::max(1, std::min(MAX_LANES, atoi(e)));
     if (const char* e = getenv("PMV_BATCH_WAIT")) E->wait_mode = !strcmp(e, "spin") ? 0 : !strcmp(e, "yield") ? 1 : 2;
-    for (int r = 0; r < R_COUNT; r++) E->comb[r].th = std::thread(combiner_loop, E, r);
+    for (int r = 0; r < R_COUNT; r++)
+        for (int l = 0; l < E->lanes; l++) {
+            Combiner& C = E->comb[r][l];
+            CKC(hipStreamCreateWithFlags(&C.s, hipStreamNonBlocking));
+            CKC(hipEventCreateWithFlags(&C.ev, hipEventBlockingSync | hipEventDisableTiming));
+            if (r == R_LK) {
+                CKC(hipHostMalloc(&C.h_out_xy, E->cap_tracks * 8, hipHostMallocMapped));
+                CKC(hipHostMalloc(&C.h_status, E->cap_tracks, hipHostMallocMapped));
+                CKC(hipHostMalloc(&C.h_err, E->cap_tracks * 4, hipHostMallocMapped));
+                CKC(hipHostGetDevicePointer((void**)&C.dm_out_xy, C.h_out_xy, 0));
+                CKC(hipHostGetDevicePointer((void**)&C.dm_status, C.h_status, 0));
+                CKC(hipHostGetDevicePointer((void**)&C.dm_err, C.h_err, 0));
+            }
+            if (r == R_DET) CKC(hipMalloc(&C.d_flags, 16));
+        }
+    for (int r = 0; r < R_COUNT; r++)
+        for (int l = 0; l < E->lanes; l++) E->comb[r][l].th = std::thread(combiner_loop, E, r, l);
     *out = E;
     return PMV_OK;
 }
 
 void batch_engine_stats(BatchEngine* E, long long* counts10, double* times15) {
-    for (int r = 0; r < R_COUNT; r++) {
-        counts10[2 * r] = E->comb[r].batches; counts10[2 * r + 1] = E->comb[r].requests;
-        if (times15) { times15[3 * r] = E->comb[r].t_cpu; times15[3 * r + 1] = E->comb[r].t_work; times15[3 * r + 2] = E->comb[r].t_sync; }
+    for (int r = 0; r < 5; r++) {   // the five classes every run uses; the optional five-point class is reported separately
+
+        counts10[2 * r] = counts10[2 * r + 1] = 0;
+        if (times15) times15[3 * r] = times15[3 * r + 1] = times15[3 * r + 2] = 0;
+        for (int l = 0; l < E->lanes; l++) {   // summed over the class's combiners
+            const Combiner& C = E->comb[r][l];
+            counts10[2 * r] += C.batches; counts10[2 * r + 1] += C.requests;
+            if (times15) { times15[3 * r] += C.t_cpu; times15[3 * r + 1] += C.t_work; times15[3 * r + 2] += C.t_sync; }
+        }
     }
 }
 
@@ -485,7 +524,7 @@ int engine_lk(BatchEngine* E, int prev_slot, int next_slot, const float* prev_xy
         const int s8 = (int)((long)i * 8 / n), first = (int)(((long)s8 * n + 7) / 8);
         r.order[(i - first) * 8 + s8] = byx[i].second;
     }
-    return submit(ctx, E->comb[R_LK], &r);
+    return submit(ctx, E->queue[R_LK], &r);
 }
 
 int engine_detect(BatchEngine* E, int kind, int slot, const int* cells, int n_cells, int max_per_cell, double quality, double min_dist, int* out_xy,
@@ -505,7 +544,7 @@ int engine_detect(BatchEngine* E, int kind, int slot, const int* cells, int n_ce
             PMV_ERR_INVALID, "detect: cell %d invalid", i);
     }
     r.quality = quality; r.min_dist = min_dist; r.out_xy = out_xy; r.out_score = out_score; r.out_count = out_count;
-    return submit(ctx, E->comb[R_DET], &r);
+    return submit(ctx, E->queue[R_DET], &r);
 }
 
 int engine_pnp(BatchEngine* E, int seq, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec, int iterations,
@@ -516,7 +555,7 @@ int engine_pnp(BatchEngine* E, int seq, const float* obj_xyz, const float* img_x
     PnPReq r;
     r.kind = 10; r.b = E->slots[seq];
     pnp_prepare(r.b, obj_xyz, img_xy, m, K, iterations, reproj_err, confidence, &r.P, &r.in_bytes);
-    rc = submit(ctx, E->comb[R_PNP], &r);
+    rc = submit(ctx, E->queue[R_PNP], &r);
     if (rc) return rc;
     pnp_finish(ctx, r.b, obj_xyz, img_xy, m, K, rvec, tvec, iterations, reproj_err, confidence, r.in_bytes, out_inliers, out_n_inliers);
     return PMV_OK;
@@ -532,7 +571,7 @@ int engine_ba(BatchEngine* E, int seq, double* cams, int nc, double* pts, int np
     r.kind = 11; r.b = E->slots[seq]; r.max_iterations = max_iterations;
     rc = ba_prepare(ctx, r.b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, true, &r.A, &r.io_bytes);
     if (rc) return rc;
-    rc = submit(ctx, E->comb[R_BA], &r);
+    rc = submit(ctx, E->queue[R_BA], &r);
     if (rc) return rc;
     ba_finish(ctx, r.b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, nullptr);
     return PMV_OK;
@@ -545,9 +584,22 @@ int engine_dlt(BatchEngine* E, int seq, const double* q1, const double* q2, int 
     DltReq r;
     r.kind = 12; r.b = E->slots[seq];
     dlt_prepare(r.b, q1, q2, n, P1x4, mask_in, &r.P, &r.in_bytes);
-    const int rc = submit(ctx, E->comb[R_DLT], &r);
+    const int rc = submit(ctx, E->queue[R_DLT], &r);
     if (rc) return rc;
     dlt_finish(ctx, r.b, q1, q2, n, P1x4, mask_in, r.in_bytes, out_Q, out_mask, out_good);
+    return PMV_OK;
+}
+
+int engine_fivepoint(BatchEngine* E, int seq, const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr, double* models,
+                     int* n_models, int* counts) {
+    pmv_ctx* ctx = E->ctx;
+    FPReq r;
+    r.kind = 13; r.b = E->slots[seq];
+    int rc = fivepoint_prepare(ctx, r.b, q1, q2, n, samples, n_hyp, thr, &r.P, &r.in_bytes);
+    if (rc) return rc;
+    rc = submit(ctx, E->queue[R_FP], &r);
+    if (rc) return rc;
+    fivepoint_finish(r.b, n_hyp, r.in_bytes, models, n_models, counts);
     return PMV_OK;
 }
 

@@ -381,7 +381,7 @@ int pmv_prof_enable(pmv_ctx* ctx, int on) {
 int pmv_prof_select(pmv_ctx* ctx, unsigned mask) {
     REQ(ctx, PMV_ERR_INVALID, "null ctx");
     ctx->prof.mask = mask;
-    ctx->prof.chain_detail = (mask >> K_BAM_EVAL0) != 0 && mask != ~0u;
+    ctx->prof.chain_detail = ((mask >> K_BAM_EVAL0) & 0x3fu) != 0 && mask != ~0u;
     return PMV_OK;
 }
 // diagnostic: phase timers of k_lk for track 0 (PMV_LK_STAMPS=1): [0] level entry, [1] I tile, [2] Scharr, [3] samples + A, [4] iterations

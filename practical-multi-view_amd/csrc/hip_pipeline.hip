@@ -103,8 +103,13 @@ struct HipPnP : EPnPSolverBase {
         return n > 0;
     }
 };
-struct HipTri : vo::FivePointTri {   // five-point RANSAC on the host, the per-point DLT + cheirality of recoverPose on the GPU
+struct HipTri : vo::FivePointTri {   // five-point RANSAC hypotheses on host threads (default) or on the GPU, recoverPose's DLT + cheirality on the GPU
     pmv_ctx* ctx;
+    bool essential_hypotheses(const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr, double* models, int* n_models,
+                              int* counts) override {
+        ck(ctx, pmv_fivepoint_hypotheses(ctx, q1, q2, n, samples, n_hyp, thr, models, n_models, counts));
+        return true;
+    }
     void dlt_candidates(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
                         uint8_t* out_mask, int* out_good) override {
         ck(ctx, pmv_triangulate_candidates(ctx, q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good));
@@ -176,6 +181,11 @@ struct BatchPnP : EPnPSolverBase {
 };
 struct BatchTri : vo::FivePointTri {
     pmv_ctx* ctx; pmv::BatchEngine* eng; int seq;
+    bool essential_hypotheses(const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr, double* models, int* n_models,
+                              int* counts) override {
+        ck(ctx, pmv::engine_fivepoint(eng, seq, q1, q2, n, samples, n_hyp, thr, models, n_models, counts));
+        return true;
+    }
     void dlt_candidates(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
                         uint8_t* out_mask, int* out_good) override {
         ck(ctx, pmv::engine_dlt(eng, seq, q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good));
@@ -242,6 +252,7 @@ int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K
         } else { auto* l = new HipLK(); l->ctx = ctx; lk = l; }
         auto* pnp = new HipPnP(); pnp->ctx = ctx; pnp->tracker = &run.pipe;
         auto* tri = new HipTri(); tri->ctx = ctx; tri->tracker = &run.pipe; tri->workers = std::max(1, P->n_threads);
+        tri->use_hypothesis_hook = P->device_fivepoint != 0;
         auto* ba = new HipBA(); ba->ctx = ctx; ba->tracker = &run.pipe;
         run.m = lk; run.p = pnp; run.tr = tri; run.b = ba;
         run.pipe.extractor = ex; run.pipe.matcher = lk; run.pipe.pnpsolver = pnp; run.pipe.triangulator = tri; run.pipe.ba = ba;
@@ -309,6 +320,7 @@ int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* param
                 auto* lk = new BatchLK(); lk->ctx = ctx; lk->eng = eng;
                 auto* pnp = new BatchPnP(); pnp->ctx = ctx; pnp->eng = eng; pnp->seq = b; pnp->tracker = &run.pipe;
                 auto* tri = new BatchTri(); tri->ctx = ctx; tri->eng = eng; tri->seq = b; tri->tracker = &run.pipe; tri->workers = 1;
+                tri->use_hypothesis_hook = P->device_fivepoint != 0;
                 auto* ba = new BatchBA(); ba->ctx = ctx; ba->eng = eng; ba->seq = b; ba->tracker = &run.pipe;
                 run.m = lk; run.p = pnp; run.tr = tri; run.b = ba;
                 run.pipe.extractor = ex; run.pipe.matcher = lk; run.pipe.pnpsolver = pnp; run.pipe.triangulator = tri; run.pipe.ba = ba;

@@ -358,7 +358,7 @@ private:
 std::shared_ptr<SpinPool> make_spin_pool(int workers) { return std::make_shared<SpinPool>(workers); }
 
 bool find_essential_mat(const double* p1, const double* p2, int n, const double* K, double prob, double threshold,
-                        double* E, std::vector<uint8_t>& mask, int* samples_drawn, SpinPool* pool, int pool_width) {
+                        double* E, std::vector<uint8_t>& mask, int* samples_drawn, SpinPool* pool, int pool_width, FivePointTri* hook) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     std::vector<double> q1(2 * n), q2(2 * n);
     for (int i = 0; i < n; i++) {
@@ -396,7 +396,38 @@ bool find_essential_mat(const double* p1, const double* p2, int n, const double*
         return true;
     }
     auto draw = [&](int* idx) { draw_subset(rng, n, modelPoints, idx); };
-    if (!pool || pool_width <= 1) {
+    bool hooked = false;
+    if (hook) {
+        // rounds of hypotheses evaluated by the plugin's kernel hook (models + inlier counts), then the sequential bookkeeping in
+        // sample order — the same replay as the helper-thread path below, so the outcome is the sequential algorithm's
+        const int B = FivePointTri::HYP_ROUND;
+        std::vector<int> idx(5 * B), nm(B), counts(10 * B);
+        std::vector<double> models_b((size_t)90 * B);
+        int iter = 0;
+        hooked = true;
+        while (iter < niters) {
+            const int nb = std::min(B, niters - iter);
+            for (int b = 0; b < nb; b++) draw(&idx[5 * b]);
+            if (!hook->essential_hypotheses(q1.data(), q2.data(), n, idx.data(), nb, thr, models_b.data(), nm.data(), counts.data())) {
+                if (iter == 0) { hooked = false; rng = RNG((uint64_t)-1); break; }   // no kernel behind the hook: host path from a fresh stream
+                return false;
+            }
+            for (int b = 0; b < nb && iter < niters; b++, iter++) {
+                if (samples_drawn) ++*samples_drawn;
+                for (int mi = 0; mi < nm[b]; mi++) {
+                    if (counts[10 * b + mi] > std::max(maxGood, modelPoints - 1)) {
+                        sampson_errors(&models_b[(size_t)90 * b + 9 * mi], q1.data(), q2.data(), n, err.data());
+                        for (int i = 0; i < n; i++) mask[i] = (uint8_t)(err[i] <= thr);
+                        memcpy(best, &models_b[(size_t)90 * b + 9 * mi], sizeof(best));
+                        maxGood = counts[10 * b + mi];
+                        niters = ransac_update_num_iters(prob, (double)(n - maxGood) / n, modelPoints, niters);
+                    }
+                }
+            }
+        }
+    }
+    if (hooked) {
+    } else if (!pool || pool_width <= 1) {
         for (int iter = 0; iter < niters; iter++) {
             if (samples_drawn) ++*samples_drawn;
             int idx[5];
@@ -570,7 +601,7 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     int drawn = 0;
     auto tE = std::chrono::steady_clock::now();
     HostCpuScope* cpu_e = new HostCpuScope(tracker->stats.hp.t[14]);
-    const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn, pool.get(), workers);
+    const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn, pool.get(), workers, use_hypothesis_hook ? this : nullptr);
     delete cpu_e;
     if (pool) pool->end();
     tracker->stats.t_tri_essential += std::chrono::duration<double>(std::chrono::steady_clock::now() - tE).count();

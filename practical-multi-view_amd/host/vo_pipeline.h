@@ -95,6 +95,16 @@ public:
     int workers = 1;                 // threads evaluating RANSAC hypotheses side by side (results do not depend on it)
     std::shared_ptr<SpinPool> pool;  // created on first use when workers > 1
     void triangulate(Frame& src, Frame& next, Mat3& R, Vec3& t) override;
+    // optional kernel hook for the RANSAC hypotheses of findEssentialMat: for n_hyp samples (5 indices each) of the n normalised
+    // correspondences return the essential matrices of every sample (models: n_hyp x 90, n_models: n_hyp) and their inlier counts
+    // under the float32 Sampson test (counts: n_hyp x 10). Return false (default) to evaluate them on host threads instead.
+    static constexpr int HYP_ROUND = 32;   // samples handed to the hook per round
+    bool use_hypothesis_hook = false;      // set by plugins that implement essential_hypotheses
+    virtual bool essential_hypotheses(const double* q1, const double* q2, int n, const int* samples, int n_hyp, float thr, double* models,
+                                      int* n_models, int* counts) {
+        (void)q1; (void)q2; (void)n; (void)samples; (void)n_hyp; (void)thr; (void)models; (void)n_models; (void)counts;
+        return false;
+    }
     // kernel hook (same contract as dlt_candidates_host); the HIP plugin overrides it with pmv_triangulate_candidates
     virtual void dlt_candidates(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
                                 uint8_t* out_mask, int* out_good) {
@@ -197,7 +207,7 @@ int five_point_update_num_iters(double p, double ep, int model_points, int max_i
 // cv::findEssentialMat(points1, points2, K, RANSAC, prob, threshold, mask) on pixel coordinates; samples_drawn counts RANSAC
 // iterations; pool/pool_width: helper threads (results do not depend on them)
 bool find_essential_mat(const double* p1, const double* p2, int n, const double* K, double prob, double threshold, double* E,
-                        std::vector<uint8_t>& mask, int* samples_drawn, SpinPool* pool, int pool_width);
+                        std::vector<uint8_t>& mask, int* samples_drawn, SpinPool* pool, int pool_width, FivePointTri* hook = nullptr);
 // cv::recoverPose(E, points1, points2, K, R, t, HUGE_VAL, mask (in/out), triangulatedPoints): returns the number of good points
 int recover_pose(FivePointTri* self, const double* E, const double* p1, const double* p2, int n, const double* K, double* R_out,
                  double* t_out, std::vector<uint8_t>& mask, std::vector<double>& tri4);

@@ -20,15 +20,16 @@ for b in range(Bmax):
     ctx.frames_stage(b * n, frames)
 ref = None
 THREADED = int(os.environ.get("THREADED", "1"))
+DEVFP = int(os.environ.get("DEVFP", "0"))
 print("wait mode", os.environ.get("PMV_BATCH_WAIT", "block"), "threaded", THREADED, flush=True)
 for B in Bs:
     seqs = [(b * n, n, gt) for b in range(B)]
-    r = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED)   # warm-up
+    r = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED, device_fivepoint=DEVFP)   # warm-up
     ctx.sync()
     s0 = ctx.batch_stats()
     t0 = time.perf_counter()
     c0 = time.process_time()
-    r2 = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED)
+    r2 = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED, device_fivepoint=DEVFP)
     ctx.sync()
     dt = time.perf_counter() - t0
     cpu = time.process_time() - c0

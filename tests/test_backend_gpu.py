@@ -191,3 +191,67 @@ def test_ba_single_workgroup_variant_agrees(gpu_ctx_factory):
     np.testing.assert_allclose(r["cost"], s.final_cost, rtol=1e-8)
     np.testing.assert_allclose(np.array(r["cams"]), cams, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(np.array(r["pts"]), pts, rtol=1e-6, atol=1e-6)
+
+
+def test_fivepoint_round_on_device_is_bit_exact(pmv, orc, gpu_ctx_factory):
+    """the hypothesis half of cv::findEssentialMat on the GPU (k_fivepoint_hyp: Nister's solver, one thread per sample;
+    k_fivepoint_score: float32 Sampson inlier counts) against the host solver that the CPU known-answer tests pin
+    (tests/test_twoview_host.py): every essential matrix bit-exact, every inlier count exact, degenerate samples give no model."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    n = 400
+    X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-3, 2, n), rng.uniform(5, 40, n)], 1)
+    rv = rng.normal(0, 0.03, 3); th = np.linalg.norm(rv); k = rv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = np.array([0.08, -0.03, -1.0]); t /= np.linalg.norm(t)
+    Xc = X @ R.T + t
+    f = 718.856
+    q1 = np.floor(X[:, :2] / X[:, 2:3] * f + rng.normal(0, 0.3, (n, 2))) / f     # integer pixels like the reference's cv::Point (Q12)
+    q2 = np.floor(Xc[:, :2] / Xc[:, 2:3] * f + rng.normal(0, 0.3, (n, 2))) / f
+    q2[::7] += rng.normal(0, 0.05, q2[::7].shape)                                 # outliers
+    nh = 32
+    samples = np.zeros((nh, 5), np.int32)
+    orc.lib.orc_host_five_point_samples(n, nh, samples.ctypes.data_as(C.POINTER(C.c_int)))
+    samples[5] = samples[5][[0, 0, 1, 2, 3]]                                      # a repeated index: rank-deficient sample
+    thr = np.float32((1.0 / f) ** 2)
+    ctx = gpu_ctx_factory(640, 480, n_slots=1, max_tracks=1024)
+    models, nm, counts = ctx.fivepoint_hypotheses(q1, q2, samples, thr)
+    f64p = C.POINTER(C.c_double)
+    x1 = np.concatenate([q1, np.ones((n, 1))], 1); x2 = np.concatenate([q2, np.ones((n, 1))], 1)
+    total = 0
+    for h in range(nh):
+        Es = np.zeros(90)
+        s1 = np.ascontiguousarray(q1[samples[h]]); s2 = np.ascontiguousarray(q2[samples[h]])
+        want = orc.lib.orc_host_five_point(s1.ctypes.data_as(f64p), s2.ctypes.data_as(f64p), Es.ctypes.data_as(f64p))
+        assert nm[h] == want, f"hypothesis {h}: {nm[h]} models on the device, {want} on the host"
+        assert np.array_equal(models[h].reshape(90)[: 9 * want], Es[: 9 * want]), f"hypothesis {h}: models are not bit-exact"
+        for mi in range(want):
+            E = Es[9 * mi: 9 * mi + 9].reshape(3, 3)
+            Ex1 = x1 @ E.T; Etx2 = x2 @ E
+            err = ((x2 * Ex1).sum(1) ** 2 / (Ex1[:, 0] ** 2 + Ex1[:, 1] ** 2 + Etx2[:, 0] ** 2 + Etx2[:, 1] ** 2)).astype(np.float32)
+            # (the count is a threshold decision on float32 values of a float64 expression: numpy's evaluation order of the sums may
+            # differ in the last bit, so points within 1e-6 relative of the threshold are excluded from the comparison)
+            sure_in = int((err <= thr * np.float32(1 - 1e-6)).sum()); sure_out = int((err > thr * np.float32(1 + 1e-6)).sum())
+            assert sure_in <= counts[h, mi] <= n - sure_out
+        total += want
+    assert nm[5] == 0 and total > 40 and counts.max() > 0.7 * n
+
+
+def test_pipeline_with_device_fivepoint_equals_host_fivepoint(pmv, gpu_ctx_factory):
+    """the triangulator's RANSAC hypotheses on the GPU (device_fivepoint = 1) or on host threads: identical features and poses,
+    for one sequence and through the batch engine"""
+    cfg = dict(w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157)
+    n = 45
+    frames, poses = pmv.synth_sequence(1002, 0, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16)
+    K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=2 * n, max_tracks=4096)
+    ctx.frames_stage(0, frames); ctx.frames_stage(n, frames)
+    a = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1, n_threads=4)
+    b = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1, device_fivepoint=1)
+    assert a.stats["tri_calls"] >= 3
+    assert np.array_equal(a.poses, b.poses)
+    for x, y in zip(a.features, b.features):
+        assert np.array_equal(x, y)
+    for r in ctx.pipeline_run_batch([(0, n, poses), (n, n, poses)], cfg["w"], cfg["h"], K, device_fivepoint=1):
+        assert np.array_equal(a.poses, r.poses)
