@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--tri-threads", type=int, default=8, help="host threads evaluating the triangulator's five-point RANSAC hypotheses")
     ap.add_argument("--kitti-seq", default="07", help="sequence used when KITTI_ROOT points at a KITTI odometry tree (default: synthetic data)")
     ap.add_argument("--poses-out", default="", help="write the estimated poses of the last step in KITTI format")
-    ap.add_argument("--batch", type=int, default=64, help="extra leg: B independent sequences through batched launches on the one GPU (0 = skip)")
+    ap.add_argument("--batch", type=int, default=128, help="extra leg: B independent sequences through batched launches on the one GPU (0 = skip); "
+                                                           "128 sequences of the metric config are 222 GB of frame slots (sized for 288 GB of HBM)")
     ap.add_argument("--batch-contexts", type=int, default=0, help="diagnostic: also run the round-1 form (B contexts x 2 host threads x 2 streams)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the pcie_inclusive (streamed from host memory) leg")
     args = ap.parse_args()
@@ -415,7 +416,14 @@ def main():
         B = args.batch
         frames, gt = data[0]
         n = frames.shape[0]
-        bc = pmv.Context(w, h, **dict(ctx_kw, n_slots=B * n, max_tracks=1024, max_ba_cams=8, max_ba_points=4096, max_ba_obs=32768))
+        bc = None
+        while bc is None:
+            try:
+                bc = pmv.Context(w, h, **dict(ctx_kw, n_slots=B * n, max_tracks=1024, max_ba_cams=8, max_ba_points=4096, max_ba_obs=32768))
+            except pmv.PmvError:      # not enough free HBM for B sequences: halve
+                if B <= 8:
+                    raise
+                B //= 2
         for b in range(B):
             bc.frames_stage(b * n, frames)     # the same frames in every slot range: a throughput leg, every run is a full independent pass
         seqs = [(b * n, n, gt) for b in range(B)]
@@ -424,16 +432,19 @@ def main():
         warm = bc.pipeline_run_batch(seqs, w, h, K, **bkw)
         bc.sync()
         s0 = bc.batch_stats()
-        bc.prof_enable(True)
         t1 = time.perf_counter()
         c1 = time.process_time()
         results = bc.pipeline_run_batch(seqs, w, h, K, **bkw)
         bc.sync()
         dtb = time.perf_counter() - t1
         cpu_b = time.process_time() - c1
+        s1 = bc.batch_stats()
+        # kernel table of the batched launches: a third pass with per-launch events on (they cost host time, so not in the timed pass)
+        bc.prof_enable(True)
+        prof_pass = bc.pipeline_run_batch(seqs, w, h, K, **bkw)
+        bc.sync()
         bc.prof_enable(False)
         bprof = bc.prof_read()
-        s1 = bc.batch_stats()
         same = all(np.array_equal(r_.poses, res.poses) for r_ in results)
         fr_b = sum(n - int(r_.stats["init_offset"]) for r_ in results)
         rounds = {}
@@ -457,7 +468,7 @@ def main():
                        combiners=rounds, kernels=bk, roofline=b_roof,
                        how="pmv_pipeline_run_batch: one host thread per sequence (unchanged adapters), five combiner threads merge the plugin calls "
                            "into batched launches (k_lk_batch, detectors, k_pnp_*_batch, k_bamB_* chain, k_tri_dlt_batch), one HIP stream per class")
-        for r_ in warm + results:
+        for r_ in warm + results + prof_pass:
             r_.free()
         bc.close()
     if args.batch_contexts > 1 and world == 1 and args.config == 1:

@@ -1589,7 +1589,7 @@ void ba_fill_prob(BAProb& P, const BAArgs& A, void* d_state, double* d_part) {
 }
 __global__ __launch_bounds__(BM_T) void k_bamB_eval0(const BAProb* __restrict__ probs) {
     const BAProb& P = probs[blockIdx.y];
-    const BAArgs A = P.A;
+    const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     const int bx = blockIdx.x;
     if (bx < P.nbo) { bam_eval0_role(A, (BAGState*)P.st2[1], P.chol_flags, P.part_cost, bx, P.nbo); return; }
     const int zb = bx - P.nbo, nzb = P.clear_blocks;
@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(BM_T) void k_bamB_eval0(const BAProb* __restrict__ 
 __global__ __launch_bounds__(BM_T) void k_bamB_campoint(const BAProb* __restrict__ probs, int it, int part) {
     __shared__ double swork[BM_WORK];
     const BAProb& P = probs[blockIdx.y];
-    const BAArgs A = P.A;
+    const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     BAGState* sin = (BAGState*)P.st2[it & 1];
     BAGState* sc = (BAGState*)P.st2[(it + 1) & 1];
     int* cf = P.chol_flags + it;
@@ -1615,23 +1615,23 @@ __global__ __launch_bounds__(64 * BG_W) void k_bamB_gemm(const BAProb* __restric
     __shared__ double swork[BG_W * 4 * 64];
     const BAProb& P = probs[blockIdx.y];
     if ((int)blockIdx.x >= P.tiles * BG_H) return;
-    const BAArgs A = P.A;
+    const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     bam_gemm_role(A, (const BAGState*)P.st2[(it + 1) & 1], blockIdx.x, swork);
 }
 __global__ __launch_bounds__(BM_T) void k_bamB_solve(const BAProb* __restrict__ probs, int it) {
     const BAProb& P = probs[blockIdx.x];
-    const BAArgs A = P.A;
+    const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     bam_solve_role(A, (BAGState*)P.st2[(it + 1) & 1], P.chol_flags + it, P.part_cost, P.nbo, P.part_gmax, P.nbp, P.Ublk, P.rhsblk, P.candrot);
 }
 __global__ __launch_bounds__(BM_T) void k_bamB_backsub(const BAProb* __restrict__ probs, int it) {
     const BAProb& P = probs[blockIdx.y];
     if ((int)blockIdx.x >= P.nbp) return;
-    const BAArgs A = P.A;
+    const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     bam_backsub_role(A, (const BAGState*)P.st2[(it + 1) & 1], P.candrot, P.tmp3, P.part4, blockIdx.x);
 }
 __global__ __launch_bounds__(BM_T) void k_bamB_finish(const BAProb* __restrict__ probs, int max_it) {
     const BAProb& P = probs[blockIdx.x];
-    const BAArgs A = P.A;
+    const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     bam_finish_role(A, (const BAGState*)P.st2[max_it & 1], P.part4, P.nbp);
 }
 hipError_t launch_ba_multi_batch(hipStream_t s, const BAProb* d_probs, const BABatchDims& D) {

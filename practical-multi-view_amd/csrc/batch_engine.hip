@@ -52,14 +52,17 @@ struct BAReq : Req { BackendBuffers* b; BAArgs A; size_t io_bytes; int max_itera
 struct DltReq : Req { BackendBuffers* b; DltProblem P; size_t in_bytes; };
 struct FPReq : Req { BackendBuffers* b; FivePointProblem P; size_t in_bytes; };
 
-struct Growable {   // device (or pinned host) buffer that only grows
-    void* p = nullptr; size_t cap = 0; bool host = false;
+struct Growable {   // device (or mapped pinned host) buffer that only grows; dev = the address kernels use (alias of a host buffer)
+    void* p = nullptr; size_t cap = 0; bool host = false; char* dev = nullptr;
     hipError_t ensure(size_t need) {
         if (need <= cap) return hipSuccess;
         if (p) { hipError_t e = host ? hipHostFree(p) : hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
         need = (need * 5 / 4 + 4095) & ~(size_t)4095;
-        hipError_t e = host ? hipHostMalloc(&p, need) : hipMalloc(&p, need);
-        if (e == hipSuccess) cap = need;
+        hipError_t e = host ? hipHostMalloc(&p, need, hipHostMallocMapped) : hipMalloc(&p, need);
+        if (e != hipSuccess) return e;
+        cap = need;
+        dev = (char*)p;
+        if (host) e = hipHostGetDevicePointer((void**)&dev, p, 0);
         return e;
     }
     void release() { if (p) { (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; cap = 0; } }
@@ -166,7 +169,7 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
         const size_t off_blocks = (sizeof(LKSeq) * lk.size() + 63) & ~(size_t)63;
         const size_t off_xy = (off_blocks + sizeof(int2) * (size_t)total_blocks + 63) & ~(size_t)63;
         const size_t bytes = off_xy + (size_t)total_tracks * 8;
-        EK(C.h_front.ensure(bytes)); EK(C.d_front.ensure(bytes));
+        EK(C.h_front.ensure(bytes));
         char* hb = (char*)C.h_front.p;
         LKSeq* hseq = (LKSeq*)hb;
         int2* hblk = (int2*)(hb + off_blocks);
@@ -180,10 +183,9 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
             memcpy(hxy + (size_t)2 * r->base, r->prev_xy, (size_t)r->n * 8);
             q++;
         }
-        EK(hipMemcpyAsync(C.d_front.p, hb, bytes, hipMemcpyHostToDevice, s));
         LKParams P;
         P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f; P.stamps = nullptr; P.counters = ctx->d_lk_counters;
-        char* db = (char*)C.d_front.p;
+        char* db = C.h_front.dev;   // mapped pinned: every block reads its (sequence, track) record and coordinates once, no copy launch
         EK(launch_lk_batch(s, ctx->d_slots, (const LKSeq*)db, (const int2*)(db + off_blocks), total_blocks, L, (const float*)(db + off_xy), P,
                            C.dm_out_xy, C.dm_status, C.dm_err));
     }
@@ -218,10 +220,9 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     {
         size_t tot_cells = 0, tot_out = 0;
         for (Group& g : groups) { g.out_off = tot_out; tot_cells += g.n_cells; tot_out += (size_t)g.n_cells * g.max_per_cell; }
-        EK(C.h_cells.ensure(tot_cells * CELL_STRIDE * 4)); EK(C.d_cells.ensure(tot_cells * CELL_STRIDE * 4));
+        EK(C.h_cells.ensure(tot_cells * CELL_STRIDE * 4));
         EK(C.d_eig.ensure(tot_cells * CELL_PIX * sizeof(double))); EK(C.d_cellmax.ensure(tot_cells * 8));
-        EK(C.d_det_xy.ensure(tot_out * 8)); EK(C.d_det_score.ensure(tot_out * 8)); EK(C.d_det_count.ensure(tot_cells * 4));
-        EK(C.h_det.ensure(tot_out * 16 + tot_cells * 4 + 64));
+        EK(C.h_det.ensure(tot_out * 16 + tot_cells * 4 + 64));   // [xy | score | count | flags], written by the kernels through the mapped alias
         int* hc = (int*)C.h_cells.p;
         size_t cpos = 0;
         for (Group& g : groups)
@@ -230,15 +231,15 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
                     int* d = hc + cpos * CELL_STRIDE;
                     d[0] = r->cells[4 * i]; d[1] = r->cells[4 * i + 1]; d[2] = r->cells[4 * i + 2]; d[3] = r->cells[4 * i + 3]; d[4] = r->slot; d[5] = d[6] = d[7] = 0;
                 }
-        EK(hipMemcpyAsync(C.d_cells.p, hc, tot_cells * CELL_STRIDE * 4, hipMemcpyHostToDevice, s));
         EK(hipMemsetAsync(C.d_flags, 0, 16, s));
         size_t c0 = 0;
         char* hd = (char*)C.h_det.p;
+        char* dd = C.h_det.dev;
         for (Group& g : groups) {
-            const int* dc = (const int*)C.d_cells.p + c0 * CELL_STRIDE;
-            int* dxy = (int*)C.d_det_xy.p + g.out_off * 2;
-            double* dsc = (double*)C.d_det_score.p + g.out_off;
-            int* dcnt = (int*)C.d_det_count.p + c0;
+            const int* dc = (const int*)C.h_cells.dev + c0 * CELL_STRIDE;
+            int* dxy = (int*)dd + g.out_off * 2;
+            double* dsc = (double*)(dd + tot_out * 8) + g.out_off;
+            int* dcnt = (int*)(dd + tot_out * 16) + c0;
             if (g.kind == 1)
                 EK(launch_gftt(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, g.min_dist, g.unlimited, (float*)C.d_eig.p + c0 * CELL_PIX,
                                (unsigned*)C.d_cellmax.p + c0, dxy, dcnt, C.d_flags));
@@ -247,10 +248,7 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
                                     (unsigned long long*)C.d_cellmax.p + c0, dxy, dsc, dcnt, C.d_flags));
             c0 += g.n_cells;
         }
-        EK(hipMemcpyAsync(hd, C.d_det_xy.p, tot_out * 8, hipMemcpyDeviceToHost, s));
-        EK(hipMemcpyAsync(hd + tot_out * 8, C.d_det_score.p, tot_out * 8, hipMemcpyDeviceToHost, s));
-        EK(hipMemcpyAsync(hd + tot_out * 16, C.d_det_count.p, tot_cells * 4, hipMemcpyDeviceToHost, s));
-        EK(hipMemcpyAsync(hd + tot_out * 16 + tot_cells * 4, C.d_flags, 4, hipMemcpyDeviceToHost, s));
+        EK(hipMemcpyAsync(hd + tot_out * 16 + tot_cells * 4, C.d_flags, 4, hipMemcpyDeviceToHost, s));   // (the kernels set the bits with atomics: device memory)
     }
     SYNC_TIMED(C);
     {
@@ -276,25 +274,28 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
 }
 
 // ---- back-end classes: the callers prepared their inputs in their slot's pinned block; one gather kernel pulls them into HBM ----
-// descriptor block of a batch: [problem records | stage-in jobs]
+// Descriptor block of a batch in mapped pinned memory: [problem records | stage-in jobs]. No DMA call is made: k_stage_in reads
+// its job list through the host alias; job 0 copies the problem records into device memory (the back-end chains read them in every
+// launch), jobs 1..n pull the requests' input blocks. (A hipMemcpyAsync is a blit kernel of its own: 83 k of them, 15 us each in
+// stream time, in a B = 64 run before this.)
 template <class Prob> struct DescBlock { Prob* hprob; StageJob* hjobs; const Prob* dprob; const StageJob* djobs; size_t bytes; };
 template <class Prob>
 hipError_t desc_block(Combiner& C, size_t n, DescBlock<Prob>& D) {
     const size_t off_jobs = (sizeof(Prob) * n + 255) & ~(size_t)255;
-    D.bytes = off_jobs + sizeof(StageJob) * n;
+    D.bytes = off_jobs + sizeof(StageJob) * (n + 1);
     hipError_t e = C.h_desc.ensure(D.bytes + 256);
     if (e != hipSuccess) return e;
-    e = C.d_desc.ensure(D.bytes + 256);
+    e = C.d_desc.ensure(off_jobs + 256);
     if (e != hipSuccess) return e;
     D.hprob = (Prob*)C.h_desc.p; D.hjobs = (StageJob*)((char*)C.h_desc.p + off_jobs);
-    D.dprob = (const Prob*)C.d_desc.p; D.djobs = (const StageJob*)((const char*)C.d_desc.p + off_jobs);
+    D.dprob = (const Prob*)C.d_desc.p; D.djobs = (const StageJob*)(C.h_desc.dev + off_jobs);
+    D.hjobs[0] = StageJob{C.h_desc.dev, (char*)C.d_desc.p, (unsigned)(sizeof(Prob) * n), 0};
+    D.hjobs += 1;   // the callers fill jobs 1..n
     return hipSuccess;
 }
 template <class Prob>
 hipError_t stage_in(Combiner& C, const DescBlock<Prob>& D, size_t n, int blocks_per_job) {
-    hipError_t e = hipMemcpyAsync(C.d_desc.p, C.h_desc.p, D.bytes, hipMemcpyHostToDevice, C.s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stage_in, dim3(blocks_per_job, (unsigned)n), dim3(256), 0, C.s, D.djobs);
+    hipLaunchKernelGGL(k_stage_in, dim3(blocks_per_job, (unsigned)(n + 1)), dim3(256), 0, C.s, D.djobs);
     return hipGetLastError();
 }
 
@@ -474,7 +475,15 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
     for (int r = 0; r < R_COUNT; r++)
         for (int l = 0; l < E->lanes; l++) {
             Combiner& C = E->comb[r][l];
-            CKC(hipStreamCreateWithFlags(&C.s, hipStreamNonBlocking));
+            // the back-end classes are chains of small launches (a BA solve: 23 of them): they get the higher stream priority so their
+            // workgroups are not queued behind the thousands of LK / detector waves of the front-end classes (PMV_BATCH_PRIO=0: all equal)
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lower = higher priority
+            static const bool use_prio = !(getenv("PMV_BATCH_PRIO") && atoi(getenv("PMV_BATCH_PRIO")) == 0);
+            const int prio = !use_prio ? prio_lo : (r == R_BA || r == R_PNP || r == R_DLT) ? prio_hi : prio_lo;
+            // (measured and dropped: confining the back-end classes to 64 / 96 CUs with hipExtStreamCreateWithCUMask: 25.4 k -> 16.2 k / 21.3 k
+            // frames/s at B = 64 - the PnP hypotheses need the whole chip; equal priorities: no difference either)
+            CKC(hipStreamCreateWithPriority(&C.s, hipStreamNonBlocking, prio));
             CKC(hipEventCreateWithFlags(&C.ev, hipEventBlockingSync | hipEventDisableTiming));
             if (r == R_LK) {
                 CKC(hipHostMalloc(&C.h_out_xy, E->cap_tracks * 8, hipHostMallocMapped));
