@@ -42,7 +42,7 @@ enum pmv_status {
     PMV_ERR_CAPACITY = -3,    /* exceeds the capacity given at pmv_ctx_create */
     PMV_ERR_HIP = -4,         /* HIP runtime error, see pmv_last_error */
     PMV_ERR_DEGENERATE = -5,  /* e.g. fewer than 5 PnP points (cv::Exception in the reference) */
-    PMV_ERR_OVERFLOW = -6     /* internal candidate list overflow */
+    PMV_ERR_OVERFLOW = -6     /* more corners than PMV_GFTT_UNLIMITED_CAP in a cell of a no-limit goodFeaturesToTrack call */
 };
 
 /* ---- context ------------------------------------------------------------------------------- */

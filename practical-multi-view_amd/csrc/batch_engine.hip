@@ -87,7 +87,7 @@ struct Combiner {
     double t_idle = 0, t_work = 0, t_sync = 0;   // seconds: waiting for requests / processing a batch / inside hipStreamSynchronize
     double t_cpu = 0;                            // CPU seconds of the combiner thread itself
     // LK staging + mapped pinned result blocks; detector buffers (only used by combiners of those classes)
-    Growable h_front{nullptr, 0, true}, d_front, h_cells{nullptr, 0, true}, d_cells, d_eig, d_cellmax, d_det_xy, d_det_score, d_det_count, h_det{nullptr, 0, true};
+    Growable h_front{nullptr, 0, true}, d_front, h_cells{nullptr, 0, true}, d_cells, d_eig, d_cellmax, d_spill, d_det_xy, d_det_score, d_det_count, h_det{nullptr, 0, true};
     float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr;
     float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr;
     int* d_flags = nullptr;
@@ -221,7 +221,7 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
         size_t tot_cells = 0, tot_out = 0;
         for (Group& g : groups) { g.out_off = tot_out; tot_cells += g.n_cells; tot_out += (size_t)g.n_cells * g.max_per_cell; }
         EK(C.h_cells.ensure(tot_cells * CELL_STRIDE * 4));
-        EK(C.d_eig.ensure(tot_cells * CELL_PIX * sizeof(double))); EK(C.d_cellmax.ensure(tot_cells * 8));
+        EK(C.d_eig.ensure(tot_cells * CELL_PIX * sizeof(double))); EK(C.d_cellmax.ensure(tot_cells * 8)); EK(C.d_spill.ensure(tot_cells * CELL_PIX * 4));
         EK(C.h_det.ensure(tot_out * 16 + tot_cells * 4 + 64));   // [xy | score | count | flags], written by the kernels through the mapped alias
         int* hc = (int*)C.h_cells.p;
         size_t cpos = 0;
@@ -242,10 +242,10 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
             int* dcnt = (int*)(dd + tot_out * 16) + c0;
             if (g.kind == 1)
                 EK(launch_gftt(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, g.min_dist, g.unlimited, (float*)C.d_eig.p + c0 * CELL_PIX,
-                               (unsigned*)C.d_cellmax.p + c0, dxy, dcnt, C.d_flags));
+                               (unsigned*)C.d_cellmax.p + c0, dxy, dcnt, C.d_flags, (unsigned*)C.d_spill.p + c0 * CELL_PIX));
             else
                 EK(launch_shitomasi(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, (double*)C.d_eig.p + c0 * CELL_PIX,
-                                    (unsigned long long*)C.d_cellmax.p + c0, dxy, dsc, dcnt, C.d_flags));
+                                    (unsigned long long*)C.d_cellmax.p + c0, dxy, dsc, dcnt, C.d_flags, (unsigned*)C.d_spill.p + c0 * CELL_PIX));
             c0 += g.n_cells;
         }
         EK(hipMemcpyAsync(hd + tot_out * 16 + tot_cells * 4, C.d_flags, 4, hipMemcpyDeviceToHost, s));   // (the kernels set the bits with atomics: device memory)
@@ -262,7 +262,7 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
         size_t c0 = 0;
         for (Group& g : groups) {
             for (DetReq* r : g.reqs) {
-                if ((g.kind == 1 && (flags & 5)) || (g.kind == 2 && (flags & 2))) { r->rc = PMV_ERR_OVERFLOW; snprintf(r->err, sizeof(r->err), "detector candidate list overflow (batched launch)"); continue; }
+                if (g.kind == 1 && (flags & 4)) { r->rc = PMV_ERR_OVERFLOW; snprintf(r->err, sizeof(r->err), "more corners than the no-limit capacity in a cell (batched launch)"); continue; }
                 const size_t o = g.out_off + (size_t)r->cell_base * g.max_per_cell;
                 memcpy(r->out_xy, hxy + o * 2, (size_t)r->n_cells * g.max_per_cell * 8);
                 if (r->out_score) memcpy(r->out_score, hsc + o, (size_t)r->n_cells * g.max_per_cell * 8);
@@ -443,7 +443,7 @@ void batch_engine_destroy(pmv_ctx* ctx) {
             if (C.th.joinable()) C.th.join();
             if (C.s) { (void)hipStreamSynchronize(C.s); (void)hipStreamDestroy(C.s); }
             if (C.ev) (void)hipEventDestroy(C.ev);
-            for (Growable* g : {&C.h_desc, &C.d_desc, &C.h_front, &C.d_front, &C.h_cells, &C.d_cells, &C.d_eig, &C.d_cellmax, &C.d_det_xy, &C.d_det_score, &C.d_det_count, &C.h_det}) g->release();
+            for (Growable* g : {&C.h_desc, &C.d_desc, &C.h_front, &C.d_front, &C.h_cells, &C.d_cells, &C.d_eig, &C.d_cellmax, &C.d_spill, &C.d_det_xy, &C.d_det_score, &C.d_det_count, &C.h_det}) g->release();
             if (C.h_out_xy) (void)hipHostFree(C.h_out_xy);
             if (C.h_err) (void)hipHostFree(C.h_err);
             if (C.h_status) (void)hipHostFree(C.h_status);

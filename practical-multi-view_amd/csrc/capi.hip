@@ -95,6 +95,7 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     CK(hipHostMalloc(&c->h_cells, MAX_CELLS * CELL_STRIDE * 4));
     CK(hipMalloc(&c->d_eig, (size_t)MAX_CELLS * CELL_PIX * sizeof(double)));   // shared by GFTT (f32) and ShiTomasi (f64)
     CK(hipMalloc(&c->d_cellmax, MAX_CELLS * 8));
+    CK(hipMalloc(&c->d_spill, (size_t)MAX_CELLS * CELL_PIX * 4));
     CK(hipMalloc(&c->d_det_xy, (size_t)MAX_CELLS * MAX_PER_CELL * 8));
     CK(hipMalloc(&c->d_det_score, (size_t)MAX_CELLS * MAX_PER_CELL * 8));
     CK(hipMalloc(&c->d_det_count, MAX_CELLS * 4));
@@ -133,7 +134,7 @@ void pmv_ctx_destroy(pmv_ctx* c) {
     hipFree(c->d_slots); hipFree(c->d_prev_xy); hipFree(c->d_out_xy); hipFree(c->d_status); hipFree(c->d_err);
     hipHostFree(c->h_prev_xy); hipHostFree(c->h_out_xy); hipHostFree(c->h_status); hipHostFree(c->h_err);
     hipFree(c->d_cells); hipFree(c->d_eig); hipFree(c->d_cellmax); hipFree(c->d_det_xy); hipFree(c->d_det_score);
-    hipFree(c->d_det_count); hipFree(c->d_flags);
+    hipFree(c->d_det_count); hipFree(c->d_flags); hipFree(c->d_spill);
     hipHostFree(c->h_det_xy); hipHostFree(c->h_det_score); hipHostFree(c->h_det_count); hipHostFree(c->h_cells);
     if (c->s_front) hipStreamDestroy(c->s_front);
     if (c->s_back) hipStreamDestroy(c->s_back);
@@ -320,13 +321,12 @@ int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int m
     CKC(hipMemcpyAsync(ctx->d_cells, ctx->h_cells, (size_t)n_cells * CELL_STRIDE * 4, hipMemcpyHostToDevice, ctx->s_front));
     CKC(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->s_front));   // overflow bits are per call: one overflow must not poison later calls
     CKC(launch_gftt(ctx->s_front, ctx->d_slots, L, ctx->d_cells, n_cells, max_per_cell, quality,
-                    min_dist, unlimited, (float*)ctx->d_eig, (unsigned*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_count, ctx->d_flags));
+                    min_dist, unlimited, (float*)ctx->d_eig, (unsigned*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_count, ctx->d_flags, ctx->d_spill));
     const size_t nxy = (size_t)n_cells * max_per_cell * 8;
     CKC(hipMemcpyAsync(ctx->h_det_xy, ctx->d_det_xy, nxy, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipMemcpyAsync(ctx->h_det_count, ctx->d_det_count, (size_t)n_cells * 4, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipMemcpyAsync(ctx->h_det_count + MAX_CELLS, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipStreamSynchronize(ctx->s_front));
-    REQ((ctx->h_det_count[MAX_CELLS] & 1) == 0, PMV_ERR_OVERFLOW, "pmv_detect_gftt: candidate list overflow");
     REQ((ctx->h_det_count[MAX_CELLS] & 4) == 0, PMV_ERR_OVERFLOW, "pmv_detect_gftt: more than %d corners in a cell with max_per_cell <= 0 (no limit)", MAX_PER_CELL);
     memcpy(out_xy, ctx->h_det_xy, nxy);
     memcpy(out_count, ctx->h_det_count, (size_t)n_cells * 4);
@@ -350,14 +350,13 @@ int pmv_detect_shitomasi(pmv_ctx* ctx, int slot, const int* cells, int n_cells, 
     CKC(hipMemcpyAsync(ctx->d_cells, ctx->h_cells, (size_t)n_cells * CELL_STRIDE * 4, hipMemcpyHostToDevice, ctx->s_front));
     CKC(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->s_front));
     CKC(launch_shitomasi(ctx->s_front, ctx->d_slots, L, ctx->d_cells, n_cells, max_per_cell, quality,
-                         ctx->d_eig, (unsigned long long*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_score, ctx->d_det_count, ctx->d_flags));
+                         ctx->d_eig, (unsigned long long*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_score, ctx->d_det_count, ctx->d_flags, ctx->d_spill));
     const size_t nxy = (size_t)n_cells * max_per_cell * 8;
     CKC(hipMemcpyAsync(ctx->h_det_xy, ctx->d_det_xy, nxy, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipMemcpyAsync(ctx->h_det_score, ctx->d_det_score, nxy, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipMemcpyAsync(ctx->h_det_count, ctx->d_det_count, (size_t)n_cells * 4, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipMemcpyAsync(ctx->h_det_count + MAX_CELLS, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipStreamSynchronize(ctx->s_front));
-    REQ((ctx->h_det_count[MAX_CELLS] & 2) == 0, PMV_ERR_OVERFLOW, "pmv_detect_shitomasi: candidate list overflow");
     memcpy(out_xy, ctx->h_det_xy, nxy);
     memcpy(out_score, ctx->h_det_score, nxy);
     memcpy(out_count, ctx->h_det_count, (size_t)n_cells * 4);

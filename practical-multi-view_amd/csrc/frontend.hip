@@ -482,8 +482,11 @@ constexpr size_t GFTT_SELECT_SHM = GFTT_CAP * 8 + 16 * 8 + 16;
 __global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ cells, const float* __restrict__ eig,
                                                       const unsigned* __restrict__ cellmax, int max_corners,
                                                       double quality, double min_dist, int unlimited, int* __restrict__ out_xy,
-                                                      int* __restrict__ out_count, int* __restrict__ flags) {
+                                                      int* __restrict__ out_count, int* __restrict__ flags, unsigned* __restrict__ spill_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // candidates 0..GFTT_CAP-1 live in LDS; a cell with more (a periodic texture can make every pixel a 3x3 maximum) keeps the rest in
+    // HBM as pixel indices (value = the thresholded response at that pixel, bit 31 = dead): no candidate list can overflow
+    unsigned* spill = spill_all + (size_t)blockIdx.x * CELL_PIX;
     float* cval = (float*)smem;                       // GFTT_CAP
     unsigned* cidx = (unsigned*)(smem + GFTT_CAP * 4); // GFTT_CAP
     unsigned long long* wbest = (unsigned long long*)(smem + GFTT_CAP * 8);  // 16
@@ -514,20 +517,23 @@ __global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ ce
         if (ismax) {
             const int slot = atomicAdd(scount, 1);
             if (slot < GFTT_CAP) { cval[slot] = v; cidx[slot] = (unsigned)(y * cw + x); }
+            else spill[slot - GFTT_CAP] = (unsigned)(y * cw + x);
         }
     }
+    __threadfence_block();
     __syncthreads();
-    int ncand = *scount;
-    if (ncand > GFTT_CAP) { if (tid == 0) atomicOr(flags, 1); ncand = GFTT_CAP; }
+    const int ncand = *scount;
     const bool use_dist = min_dist >= 1.0;
     const double md2 = min_dist * min_dist;
     int naccepted = 0;
     for (int it = 0; it < max_corners; it++) {
         unsigned long long best = 0;
         for (int i = tid; i < ncand; i += 1024) {
-            const float v = cval[i];
-            if (v > 0.f) {   // dead candidates are marked with -1
-                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | cidx[i];
+            float v; unsigned ci;
+            if (i < GFTT_CAP) { v = cval[i]; ci = cidx[i]; }   // dead candidates are marked with -1
+            else { ci = spill[i - GFTT_CAP]; v = (ci >> 31) ? -1.f : E[ci]; }
+            if (v > 0.f) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | ci;
                 best = key > best ? key : best;
             }
         }
@@ -546,21 +552,25 @@ __global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ ce
         }
         naccepted++;
         for (int i = tid; i < ncand; i += 1024) {
-            if (cval[i] <= 0.f) continue;
-            const int ci = (int)cidx[i];
+            int ci;
+            if (i < GFTT_CAP) { if (cval[i] <= 0.f) continue; ci = (int)cidx[i]; }
+            else { const unsigned u = spill[i - GFTT_CAP]; if (u >> 31) continue; ci = (int)u; }
+            bool kill;
             if (use_dist) {
                 const int y = ci / cw, x = ci - y * cw;
                 const int dx = x - bx, dy = y - by;
-                if ((double)(dx * dx + dy * dy) < md2) cval[i] = -1.f;
-            } else if (ci == bidx) cval[i] = -1.f;
+                kill = (double)(dx * dx + dy * dy) < md2;
+            } else kill = ci == bidx;
+            if (kill) { if (i < GFTT_CAP) cval[i] = -1.f; else spill[i - GFTT_CAP] = (unsigned)ci | 0x80000000u; }
         }
+        __threadfence_block();
         __syncthreads();
     }
     // cv::goodFeaturesToTrack(maxCorners <= 0) has no limit; here the caller's buffer holds max_corners: more corners than that
     // is reported (bit 2), not silently truncated
     if (unlimited && naccepted == max_corners) {
         int live = 0;
-        for (int i = tid; i < ncand; i += 1024) live |= cval[i] > 0.f;
+        for (int i = tid; i < ncand; i += 1024) live |= i < GFTT_CAP ? (cval[i] > 0.f) : !(spill[i - GFTT_CAP] >> 31);
         if (live) atomicOr(flags, 4);
     }
     if (tid == 0) out_count[cell] = naccepted;
@@ -568,8 +578,8 @@ __global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ ce
 
 hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                        int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,
-                       int* d_out_xy, int* d_out_count, int* d_flags) {
-    if (!slots || !d_cells || !d_eig || !d_cellmax || !d_out_xy || !d_out_count || !d_flags || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
+                       int* d_out_xy, int* d_out_count, int* d_flags, unsigned* d_spill) {
+    if (!slots || !d_cells || !d_eig || !d_cellmax || !d_out_xy || !d_out_count || !d_flags || !d_spill || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned) * n_cells, s);
     if (e != hipSuccess) return e;
     { ProfScope ps(K_GFTT_EIG, s);
@@ -577,7 +587,7 @@ hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, 
     ProfScope ps2(K_GFTT_SELECT, s);
     const size_t shm = GFTT_SELECT_SHM;   // opt-in above 64 KB: frontend_prepare_device(), once per context on its device
     hipLaunchKernelGGL(k_gftt_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_eig, d_cellmax, max_per_cell,
-                       quality, min_dist, unlimited, d_out_xy, d_out_count, d_flags);
+                       quality, min_dist, unlimited, d_out_xy, d_out_count, d_flags, d_spill);
     return hipGetLastError();
 }
 
@@ -649,8 +659,9 @@ __global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cell
                                                     const unsigned long long* __restrict__ cellmax, int max_feats,
                                                     double quality, int* __restrict__ out_xy,
                                                     double* __restrict__ out_score, int* __restrict__ out_count,
-                                                    int* __restrict__ flags) {
+                                                    int* __restrict__ flags, unsigned* __restrict__ spill_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* spill = spill_all + (size_t)blockIdx.x * CELL_PIX;   // candidates beyond ST_CAP: pixel indices in HBM (bit 31 = taken), see k_gftt_select
     unsigned long long* ckey = (unsigned long long*)smem;              // ST_CAP: ordered score key, 0 = dead
     unsigned* cidx = (unsigned*)(smem + ST_CAP * 8);                   // ST_CAP
     unsigned long long* wk = (unsigned long long*)(smem + ST_CAP * 12);// 16
@@ -669,18 +680,20 @@ __global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cell
         if (v > thr) {
             const int slot = atomicAdd(scount, 1);
             if (slot < ST_CAP) { ckey[slot] = f64_key(v); cidx[slot] = (unsigned)idx; }
+            else spill[slot - ST_CAP] = (unsigned)idx;
         }
     }
+    __threadfence_block();
     __syncthreads();
-    int ncand = *scount;
-    if (ncand > ST_CAP) { if (tid == 0) atomicOr(flags, 2); ncand = ST_CAP; }
+    const int ncand = *scount;
     int nacc = 0;
     for (int it = 0; it < max_feats; it++) {
         // best = highest score, ties -> lowest raster index (stable sort of a raster-ordered list)
         unsigned long long bk = 0; unsigned bi = 0xffffffffu;
         for (int i = tid; i < ncand; i += 1024) {
-            const unsigned long long k = ckey[i];
-            const unsigned ci = cidx[i];
+            unsigned long long k; unsigned ci;
+            if (i < ST_CAP) { k = ckey[i]; ci = cidx[i]; }
+            else { ci = spill[i - ST_CAP]; k = (ci >> 31) ? 0ull : f64_key(R[ci]); }
             if (k > bk || (k == bk && k != 0 && ci < bi)) { bk = k; bi = ci; }
         }
 #pragma unroll
@@ -702,8 +715,11 @@ __global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cell
             out_score[(size_t)cell * max_feats + nacc] = f64_unkey(bk);
         }
         nacc++;
-        for (int i = tid; i < ncand; i += 1024)
-            if (cidx[i] == bi) ckey[i] = 0;
+        for (int i = tid; i < ncand; i += 1024) {
+            if (i < ST_CAP) { if (cidx[i] == bi) ckey[i] = 0; }
+            else if (spill[i - ST_CAP] == bi) spill[i - ST_CAP] = bi | 0x80000000u;
+        }
+        __threadfence_block();
         __syncthreads();
     }
     if (tid == 0) out_count[cell] = nacc;
@@ -711,8 +727,8 @@ __global__ __launch_bounds__(1024) void k_st_select(const int* __restrict__ cell
 
 hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                             int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,
-                            int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags) {
-    if (!slots || !d_cells || !d_resp || !d_cellmax || !d_out_xy || !d_out_score || !d_out_count || !d_flags || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
+                            int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags, unsigned* d_spill) {
+    if (!slots || !d_cells || !d_resp || !d_cellmax || !d_out_xy || !d_out_score || !d_out_count || !d_flags || !d_spill || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned long long) * n_cells, s);
     if (e != hipSuccess) return e;
     { ProfScope ps(K_ST_RESP, s);
@@ -720,7 +736,7 @@ hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slots, const PyrLayout
     ProfScope ps2(K_ST_SELECT, s);
     const size_t shm = ST_SELECT_SHM;
     hipLaunchKernelGGL(k_st_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_resp, d_cellmax, max_per_cell,
-                       quality, d_out_xy, d_out_score, d_out_count, d_flags);
+                       quality, d_out_xy, d_out_score, d_out_count, d_flags, d_spill);
     return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ struct pmv_ctx {
     int* h_cells = nullptr;   // pinned staging of the device cell records
     double* d_eig = nullptr;
     void* d_cellmax = nullptr;
+    unsigned* d_spill = nullptr;   // detector candidates beyond the LDS lists: MAX_CELLS * CELL_PIX pixel indices
     int *d_det_xy = nullptr, *d_det_count = nullptr, *d_flags = nullptr;
     double* d_det_score = nullptr;
     int *h_det_xy = nullptr, *h_det_count = nullptr;

@@ -117,10 +117,10 @@ constexpr int CELL_STRIDE = 8;
 // GFTT: eig maps (n_cells * 255*255 floats), cell max (n_cells uint32 ordered keys), outputs
 hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                        int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,
-                       int* d_out_xy, int* d_out_count, int* d_flags);
+                       int* d_out_xy, int* d_out_count, int* d_flags, unsigned* d_spill /* n_cells * CELL_PIX candidate overflow area */);
 hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                             int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,
-                            int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags);
+                            int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags, unsigned* d_spill);
 
 constexpr int CELL_MAX = 255;                 // OdometryPipeline.h:31 grid_size
 constexpr int CELL_PIX = CELL_MAX * CELL_MAX;
