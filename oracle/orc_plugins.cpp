@@ -243,6 +243,23 @@ int orc_host_motion_heuristics(int n, const double* R, const double* t, const do
     memcpy(R_rel, pl.R_s.back().m, 72); memcpy(t_rel, pl.t_s.back().v, 24);
     return (int)pl.stats.heuristic_motion;
 }
+// NeighborGrid (the occupancy-grid form of the re-detection's hasNeighbor loop) against Frame::hasNeighbor itself: the map holds the
+// n_map given features; candidate i is tested by both, and - as the pipeline does - added (with its `add` coordinates) when it has no
+// neighbour. out[i] = grid answer | (scan answer << 1).
+void orc_host_neighbor_grid(const int* map_xy, int n_map, const int* cand_xy, const int* add_xy, int n_cand, int* out) {
+    vo::Frame fr;
+    for (int i = 0; i < n_map; i++) fr.map[std::make_shared<vo::Feature>(map_xy[2 * i], map_xy[2 * i + 1])] = std::weak_ptr<vo::Feature3D>();
+    vo::NeighborGrid grid(fr);
+    for (int i = 0; i < n_cand; i++) {
+        vo::Feature f(cand_xy[2 * i], cand_xy[2 * i + 1]);
+        const bool a = grid.hasNeighbor(f.column, f.row), b = fr.hasNeighbor(f);
+        out[i] = (a ? 1 : 0) | (b ? 2 : 0);
+        if (!b) {
+            fr.map[std::make_shared<vo::Feature>(add_xy[2 * i], add_xy[2 * i + 1])] = std::weak_ptr<vo::Feature3D>();
+            grid.add(add_xy[2 * i], add_xy[2 * i + 1]);
+        }
+    }
+}
 // ---- two-view geometry probes (vo_fivepoint.cpp; the host triangulator is shared by product and oracle pipelines, so its
 // known-answer tests go straight at the functions, not through a pipeline) ----
 int orc_host_five_point(const double* q1, const double* q2, double* E_out) { return vo::five_point_essentials(q1, q2, E_out); }

@@ -387,9 +387,10 @@ void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
     fmap feat_corr = matcher->matchFeatures(*(frames[frame.frame - 1]), frame);
     stats.t_lk += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
     stats.lk_calls++; stats.lk_points += (long)frames[frame.frame - 1]->map.size();
-    frames[frame.frame - 1]->feat_corr = feat_corr;
+    const int n_corr = (int)feat_corr.size();
+    frames[frame.frame - 1]->feat_corr = std::move(feat_corr);   // (the reference copies; the local is not used again)
     index_feat_corr(*frames[frame.frame - 1]);
-    if ((int)feat_corr.size() < cfg.tracked_features_tol) {
+    if (n_corr < cfg.tracked_features_tol) {
         std::vector<GridSection> roi = getGridROI(*(frames[frames.size() - 1]));   // cells of the PREVIOUS frame (quirk Q3)
         const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
         std::vector<Frame> cells;
@@ -398,16 +399,18 @@ void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
         std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
         stats.t_detect += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
         stats.detect_calls++;
+        NeighborGrid near(frame);   // frame.hasNeighbor(f) for every candidate, without the scan per candidate
         for (size_t k = 0; k < roi.size(); k++)
             for (auto& f : all[k]) {
-                if (!frame.hasNeighbor(f)) {   // cell-LOCAL coordinates vs the global map (quirk Q4)
+                if (!near.hasNeighbor(f.column, f.row)) {   // cell-LOCAL coordinates vs the global map (quirk Q4)
                     f.column = roi[k].x * cfg.grid_size[1] + f.column;
                     f.row = roi[k].y * cfg.grid_size[0] + f.row;
                     frame.map[std::make_shared<Feature>(f)] = std::weak_ptr<Feature3D>();
+                    near.add(f.column, f.row);
                 }
             }
     }
-    frames.push_back(std::make_shared<Frame>(frame));
+    frames.push_back(std::make_shared<Frame>(std::move(frame)));   // (the reference copies; callers only read frame.frame afterwards)
 }
 
 void OdometryPipeline::motionHeuristics(Mat3& _R, Vec3& _t, int j) {   // :171-208
@@ -527,9 +530,10 @@ void OdometryPipeline::run_threaded() {
         fmap feat_corr = matcher->matchFeatures(*prev, frame);
         stats.t_lk += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
         stats.lk_calls++; stats.lk_points += (long)prev->map.size();
-        prev->feat_corr = feat_corr;
+        const int n_corr = (int)feat_corr.size();
+        prev->feat_corr = std::move(feat_corr);
         index_feat_corr(*prev);
-        if ((int)feat_corr.size() < cfg.tracked_features_tol) {
+        if (n_corr < cfg.tracked_features_tol) {
             std::vector<GridSection> roi = getGridROI(*prev);
             const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
             std::vector<Frame> cells;
@@ -538,20 +542,24 @@ void OdometryPipeline::run_threaded() {
             std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
             stats.t_detect += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
             stats.detect_calls++;
+            NeighborGrid near(frame);
             for (size_t k = 0; k < roi.size(); k++)
                 for (auto& f : all[k])
-                    if (!frame.hasNeighbor(f)) {
+                    if (!near.hasNeighbor(f.column, f.row)) {
                         f.column = roi[k].x * cfg.grid_size[1] + f.column;
                         f.row = roi[k].y * cfg.grid_size[0] + f.row;
                         frame.map[std::make_shared<Feature>(f)] = std::weak_ptr<Feature3D>();
+                        near.add(f.column, f.row);
                     }
         }
+        const int frame_no = frame.frame;
+        std::shared_ptr<Frame> stored = std::make_shared<Frame>(std::move(frame));   // built outside the lock
         {
             std::unique_lock<std::mutex> lk(mu);
-            frames.push_back(std::make_shared<Frame>(frame));
-            if (frame.frame >= 2) { jobs.push_back(frame.frame - 2); cv.notify_one(); }
+            frames.push_back(std::move(stored));
+            if (frame_no >= 2) { jobs.push_back(frame_no - 2); cv.notify_one(); }
         }
-        if (on_frame_added) on_frame_added(frame.frame);
+        if (on_frame_added) on_frame_added(frame_no);
     }
     } catch (...) { front_error = std::current_exception(); }
     { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_one(); }

@@ -165,6 +165,37 @@ public:
 
 typedef std::unordered_map<std::weak_ptr<Feature>, std::weak_ptr<Feature>, Feature::Hasher, Feature::WeakEq> fmap;
 
+// Frame::hasNeighbor for many candidates against one (growing) feature set: the reference runs its O(N) scan per candidate
+// (OdometryPipeline.cpp:359-366, 2000 x 1350 distance evaluations per re-detection at configs[3]); an occupancy grid with
+// `dist`-sized buckets answers the same question — is there a feature with Chebyshev distance < dist — from the 3 x 3 buckets around
+// the candidate. Same boolean for every candidate, including features added while the loop runs (add()).
+class NeighborGrid {
+public:
+    explicit NeighborGrid(const Frame& fr, int dist_ = 5) : dist(dist_) {
+        cells.reserve(fr.map.size() * 2 + 16);
+        for (auto& p : fr.map) add(p.first->column, p.first->row);
+    }
+    void add(int column, int row) { cells[key(bucket(column), bucket(row))].push_back({column, row}); }
+    bool hasNeighbor(int column, int row) const {
+        const int bx = bucket(column), by = bucket(row);
+        for (int j = -1; j <= 1; j++)
+            for (int i = -1; i <= 1; i++) {
+                auto it = cells.find(key(bx + i, by + j));
+                if (it == cells.end()) continue;
+                for (auto& q : it->second) {
+                    const int x = std::abs(column - q.first), y = std::abs(row - q.second);
+                    if ((float)(x > y ? x : y) < dist) return true;   // Feature::distance(f) < dist
+                }
+            }
+        return false;
+    }
+private:
+    int dist;
+    std::unordered_map<long long, std::vector<std::pair<int, int>>> cells;
+    int bucket(int v) const { return v >= 0 ? v / dist : -((-v + dist - 1) / dist); }   // floor division
+    static long long key(int bx, int by) { return ((long long)bx << 32) ^ (long long)(unsigned)by; }
+};
+
 // ---- plugin interfaces (Base*.h) --------------------------------------------------------------------------
 class BaseFeatureExtractor {
 public:
