@@ -155,6 +155,9 @@ __device__ double epnp_R_and_t(const EpnpShared& sh, const double* betas, double
 }
 
 // hypothesis h of one RANSAC problem, executed by one wavefront. models: n_hyp x 6 (rvec, tvec)
+// LDS_L: the Gauss-Newton passes read L_6x10 / rho from LDS instead of a register copy - 130 fewer registers (two wavefronts per SIMD
+// instead of one) for a longer chain; the throughput form used by the batched launch. Same expressions either way.
+template <bool LDS_L>
 __device__ __forceinline__ void pnp_hyp_body(const float* __restrict__ obj, const float* __restrict__ img,
                                              const int* __restrict__ samples, const double* __restrict__ K,
                                              double* __restrict__ models, int m, float thr, uint8_t* __restrict__ masks,
@@ -337,9 +340,13 @@ __device__ __forceinline__ void pnp_hyp_body(const float* __restrict__ obj, cons
     // the three EPnP cases (N = 1, 2, 3 null-space vectors) are independent: lanes 0..2 evaluate them side by side
     if (lane < 3) {
         const int N = lane + 1;
-        double L[60], rho[6], betas[4];
-        for (int i = 0; i < 60; i++) L[i] = sh.L[i];
-        for (int i = 0; i < 6; i++) rho[i] = sh.rho[i];
+        double Lr[LDS_L ? 1 : 60], rhor[LDS_L ? 1 : 6], betas[4];
+        if (!LDS_L) {
+            for (int i = 0; i < 60; i++) Lr[i] = sh.L[i];
+            for (int i = 0; i < 6; i++) rhor[i] = sh.rho[i];
+        }
+        const double* L = LDS_L ? sh.L : Lr;
+        const double* rho = LDS_L ? sh.rho : rhor;
         // find_betas_approx_1/2/3: least squares on 4 / 3 / 5 columns of L_6x10. The three lanes run ONE code path (lanes of a
         // wavefront that take different paths execute them one after the other): the 6x4 and 6x3 systems are padded with zero
         // columns to 6x5. Padding is exact: the padded rows/columns of A^T A are zero and stay zero, the cyclic Jacobi skips
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, c
                                                 const int* __restrict__ samples, const double* __restrict__ K,
                                                 double* __restrict__ models, int m, float thr, uint8_t* __restrict__ masks,
                                                 int* __restrict__ counts, unsigned long long* stamps) {
-    pnp_hyp_body(obj, img, samples, K, models, m, thr, masks, counts, stamps, blockIdx.x);
+    pnp_hyp_body<false>(obj, img, samples, K, models, m, thr, masks, counts, stamps, blockIdx.x);
 }
 __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restrict__ obj, const float* __restrict__ img, int m,
                                                            const double* __restrict__ K, const double* __restrict__ models,
@@ -720,10 +727,28 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
     pnp_select_refit_body(obj, img, m, K, models, masks, counts, n_hyp, confidence, rt_out, inliers, info, host_out, stamps);
 }
 // batched forms: blockIdx.y = problem (several sequences' PnP calls in one launch), same per-problem arithmetic
-__global__ __launch_bounds__(64) void k_pnp_hyp_batch(const PnPProblem* __restrict__ probs) {
+// Two launches per round: hypotheses [0, h0) and [h0, n_hyp). A wavefront of the second launch first replays the sequential RANSAC
+// bookkeeping over the counts of the first h0 hypotheses (the same loop as pnp_select_refit_body): when the adaptive iteration count
+// has already dropped to <= h0, the sequential algorithm never reaches this hypothesis, nothing downstream reads its model, mask or
+// count, and the wavefront returns at once. (cv::solvePnPRansac on typical inlier ratios stops after ~10-20 of its 100 iterations;
+// the single-sequence launch evaluates all 100 side by side because it is bound by one hypothesis' latency, the batched launch
+// is bound by how many wavefronts the chip can hold.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pnp_hyp_batch(const PnPProblem* __restrict__ probs, int h0, int replay) {
     const PnPProblem p = probs[blockIdx.y];
-    if ((int)blockIdx.x >= p.n_hyp) return;
-    pnp_hyp_body(p.obj, p.img, p.samples, p.K, p.models, p.m, p.thr, p.masks, p.counts, nullptr, blockIdx.x);
+    const int h = h0 + (int)blockIdx.x;
+    if (h >= p.n_hyp) return;
+    if (replay) {
+        int maxGood = 0, niters = p.n_hyp > 1 ? p.n_hyp : 1;
+        for (int iter = 0; iter < niters && iter < h0; iter++) {
+            const int good = p.counts[iter];
+            if (good > (maxGood > 4 ? maxGood : 4)) {
+                maxGood = good;
+                niters = d_ransac_update_num_iters(p.confidence, (double)(p.m - good) / p.m, 5, niters);
+            }
+        }
+        if (niters <= h0) return;   // wave-uniform
+    }
+    pnp_hyp_body<true>(p.obj, p.img, p.samples, p.K, p.models, p.m, p.thr, p.masks, p.counts, nullptr, h);
 }
 __global__ __launch_bounds__(RF_T) void k_pnp_select_refit_batch(const PnPProblem* __restrict__ probs) {
     const PnPProblem p = probs[blockIdx.x];
@@ -733,8 +758,14 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit_batch(const PnPProble
 hipError_t launch_pnp_batch(hipStream_t s, const PnPProblem* d_probs, int n_probs, int max_hyp) {
     if (n_probs <= 0) return hipSuccess;
     if (!d_probs || max_hyp < 1) return hipErrorInvalidValue;
+    static const int stage1 = getenv("PMV_PNP_STAGE1") ? atoi(getenv("PMV_PNP_STAGE1")) : 16;
+    const int h0 = stage1 > 0 && stage1 < max_hyp ? stage1 : max_hyp;
     { ProfScope ps(K_PNP_HYP, s);
-    hipLaunchKernelGGL(k_pnp_hyp_batch, dim3(max_hyp, n_probs), dim3(64), 0, s, d_probs); }
+    hipLaunchKernelGGL(k_pnp_hyp_batch, dim3(h0, n_probs), dim3(64), 0, s, d_probs, 0, 0); }
+    if (h0 < max_hyp) {
+        ProfScope ps(K_PNP_HYP, s);
+        hipLaunchKernelGGL(k_pnp_hyp_batch, dim3(max_hyp - h0, n_probs), dim3(64), 0, s, d_probs, h0, 1);
+    }
     ProfScope ps3(K_PNP_REFIT, s);
     hipLaunchKernelGGL(k_pnp_select_refit_batch, dim3(n_probs), dim3(RF_T), 0, s, d_probs);
     return hipGetLastError();

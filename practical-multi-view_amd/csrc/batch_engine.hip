@@ -15,6 +15,7 @@
 #include "pmv_ctx.h"
 #include "backend.h"
 #include "batch_engine.h"
+#include <sys/prctl.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -91,7 +92,12 @@ struct Combiner {
     float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr;
     float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr;
     int* d_flags = nullptr;
+    // completion word of the "flag" wait: the last launch of a round is k_signal, which stores the round number into mapped pinned memory
+    unsigned* h_done = nullptr; unsigned* dm_done = nullptr; unsigned done_seq = 0;
+    double ema_wait_us = 0;            // smoothed duration of the wait of a round (how long to sleep before the first look)
 };
+
+__global__ void k_signal(unsigned* done, unsigned seq) { __threadfence_system(); __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // one input block to pull from mapped pinned host memory into HBM (16-byte granules; both buffers have >= 16 B of slack)
 struct StageJob { const char* src; char* dst; unsigned bytes, pad; };
@@ -109,12 +115,14 @@ struct BatchEngine {
     pmv_ctx* ctx = nullptr;
     int B = 0;
     int linger_us = 0;
-    int wait_mode = 2;   // 0 spin (hipStreamSynchronize), 1 query + yield, 2 blocking event
+    int wait_mode = 3;   // 0 spin (hipStreamSynchronize), 1 query + yield, 2 blocking event, 3 completion word + timed sleeps
     std::vector<BackendBuffers*> slots;   // one back-end workspace set per concurrent sequence
     int lanes = 1;   // measured: 2 and 3 combiners per class cost more host CPU (smaller batches) than they win in latency: 25.7k -> 23.3k -> 19.5k frames/s at B = 64
     Queue queue[R_COUNT];
     Combiner comb[R_COUNT][MAX_LANES];
     size_t cap_tracks = 0;
+    bool exclusive = false;
+    std::mutex exclusive_mu;
 };
 
 namespace {
@@ -139,9 +147,35 @@ hipError_t wait_stream(BatchEngine* E, Combiner& C) {
             std::this_thread::yield();
         }
     }
-    hipError_t e = hipEventRecord(C.ev, C.s);
+    if (E->wait_mode == 2) {
+        // (measured: with a blocking-sync event the runtime still spins 100 + 200 us before it sleeps in the driver - for rounds of
+        // 0.15-1.4 ms the five combiner threads burned 17 of the 59 CPU-seconds of a B = 128 run)
+        hipError_t e = hipEventRecord(C.ev, C.s);
+        if (e != hipSuccess) return e;
+        return hipEventSynchronize(C.ev);
+    }
+    // completion word: sleep through most of the expected duration, then look every ~10 us (timer slack of the thread is 1 us)
+    const unsigned seq = ++C.done_seq;
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, C.s, C.dm_done, seq);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return hipEventSynchronize(C.ev);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto done = [&] { return __atomic_load_n(C.h_done, __ATOMIC_ACQUIRE) == seq; };
+    if (!done()) {
+        const double first = 0.7 * C.ema_wait_us;
+        if (first > 25) std::this_thread::sleep_for(std::chrono::nanoseconds((long)(first * 1e3)));
+        int looks = 0;
+        while (!done()) {
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
+            if ((++looks & 255) == 0) {   // a faulted launch never signals: ask the runtime now and then
+                e = hipStreamQuery(C.s);
+                if (e != hipSuccess && e != hipErrorNotReady) return e;
+            }
+        }
+    }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    C.ema_wait_us = C.ema_wait_us == 0 ? us : 0.8 * C.ema_wait_us + 0.2 * us;
+    return hipSuccess;
 }
 
 // ---- LK -------------------------------------------------------------------------------------------------------------------------
@@ -381,6 +415,7 @@ void combiner_loop(BatchEngine* E, int role, int lane) {
     Queue* Q = &E->queue[role];
     (void)hipSetDevice(E->ctx->device);
     tl_prof = &E->ctx->prof;
+    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   // 1 us instead of the default 50 us: the timed sleeps of wait_stream
     for (;;) {
         std::vector<Req*> batch;
         const auto ti = std::chrono::steady_clock::now();
@@ -397,6 +432,9 @@ void combiner_loop(BatchEngine* E, int role, int lane) {
         }
         const auto tw = std::chrono::steady_clock::now();
         C->t_idle += std::chrono::duration<double>(tw - ti).count();
+        // diagnostic (PMV_BATCH_EXCLUSIVE=1): one class on the GPU at a time, so a round's duration is that of its kernels alone
+        std::unique_lock<std::mutex> excl(E->exclusive_mu, std::defer_lock);
+        if (E->exclusive) excl.lock();
         switch (role) {
         case R_LK: process_lk(E, *C, batch); break;
         case R_DET: process_det(E, *C, batch); break;
@@ -405,6 +443,7 @@ void combiner_loop(BatchEngine* E, int role, int lane) {
         case R_DLT: process_dlt(E, *C, batch); break;
         default: process_fp(E, *C, batch); break;
         }
+        if (E->exclusive) excl.unlock();
         {
             std::lock_guard<std::mutex> lk(Q->mu);
             C->batches++; C->requests += (long)batch.size();
@@ -443,6 +482,7 @@ void batch_engine_destroy(pmv_ctx* ctx) {
             if (C.th.joinable()) C.th.join();
             if (C.s) { (void)hipStreamSynchronize(C.s); (void)hipStreamDestroy(C.s); }
             if (C.ev) (void)hipEventDestroy(C.ev);
+            if (C.h_done) (void)hipHostFree(C.h_done);
             for (Growable* g : {&C.h_desc, &C.d_desc, &C.h_front, &C.d_front, &C.h_cells, &C.d_cells, &C.d_eig, &C.d_cellmax, &C.d_spill, &C.d_det_xy, &C.d_det_score, &C.d_det_count, &C.h_det}) g->release();
             if (C.h_out_xy) (void)hipHostFree(C.h_out_xy);
             if (C.h_err) (void)hipHostFree(C.h_err);
@@ -470,8 +510,9 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
         if (rc != PMV_OK) { batch_engine_destroy(ctx); return rc; }
     }
     E->cap_tracks = (size_t)B * ctx->max_tracks;
+    if (const char* e = getenv("PMV_BATCH_EXCLUSIVE")) E->exclusive = atoi(e) != 0;
     if (const char* e = getenv("PMV_BATCH_LANES")) E->lanes = std::max(1, std::min(MAX_LANES, atoi(e)));
-    if (const char* e = getenv("PMV_BATCH_WAIT")) E->wait_mode = !strcmp(e, "spin") ? 0 : !strcmp(e, "yield") ? 1 : 2;
+    if (const char* e = getenv("PMV_BATCH_WAIT")) E->wait_mode = !strcmp(e, "spin") ? 0 : !strcmp(e, "yield") ? 1 : !strcmp(e, "block") ? 2 : 3;
     for (int r = 0; r < R_COUNT; r++)
         for (int l = 0; l < E->lanes; l++) {
             Combiner& C = E->comb[r][l];
@@ -485,6 +526,9 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
             // frames/s at B = 64 - the PnP hypotheses need the whole chip; equal priorities: no difference either)
             CKC(hipStreamCreateWithPriority(&C.s, hipStreamNonBlocking, prio));
             CKC(hipEventCreateWithFlags(&C.ev, hipEventBlockingSync | hipEventDisableTiming));
+            CKC(hipHostMalloc(&C.h_done, 64, hipHostMallocMapped));
+            *C.h_done = 0;
+            CKC(hipHostGetDevicePointer((void**)&C.dm_done, C.h_done, 0));
             if (r == R_LK) {
                 CKC(hipHostMalloc(&C.h_out_xy, E->cap_tracks * 8, hipHostMallocMapped));
                 CKC(hipHostMalloc(&C.h_status, E->cap_tracks, hipHostMallocMapped));

@@ -127,6 +127,23 @@ __device__ inline void block_sum_exact(const int (&part)[N], double (&out)[N], d
     }
 }
 
+// NB consecutive bytes that start at byte `off` (any alignment) of an LDS row whose base is 4-byte aligned, fetched as aligned dword
+// loads and shifted into place: e[j] holds bytes 4j .. 4j+3 of the run. A byte load serves one pixel per LDS instruction; this serves
+// four, and with lanes = distinct rows of an odd dword stride the dword loads are free of bank conflicts. `off & 3` must be
+// wave-uniform in practice (it is: tile origin + a multiple of 4), but nothing here depends on it.
+template <int NB>
+__device__ inline void lds_row_bytes(const uint8_t* row, int off, uint32_t (&e)[(NB + 3) / 4]) {
+    constexpr int ND = (NB + 3 + 3) / 4, NE = (NB + 3) / 4;
+    const uint32_t* w = (const uint32_t*)row + (off >> 2);
+    const uint32_t sh = (uint32_t)off & 3u;
+    uint32_t d[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) d[j] = w[j];
+#pragma unroll
+    for (int j = 0; j < NE; j++) e[j] = __builtin_amdgcn_alignbyte(j + 1 < ND ? d[j + 1] : 0u, d[j], sh);
+}
+#define PACKED_BYTE(e, k) ((int)(((e)[(k) >> 2] >> (((k) & 3) * 8)) & 0xffu))
+
 // 64x64-byte search tile, dword copies (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0): 1024 dwords over T threads
 template <int T>
 __device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0, int ty0, int tid) {
@@ -147,13 +164,15 @@ struct LKResult { float x, y, err; int status, n_iter, n_lev; };
 template <int T>
 __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS, const PyrLayout& L,
                                                    const float px0, const float py0, const LKParams& P, const bool stamp_on) {
-    __shared__ __attribute__((aligned(16))) uint8_t sI[35 * SI_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t sI[35 * SI_STRIDE + 4];   // + one dword: the aligned loads of the last row may touch it
     __shared__ __attribute__((aligned(16))) short2 sD[33 * SD_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t sJ[64 * SJ_STRIDE];
     __shared__ double sred[2 * (T / 64) * 4];
     constexpr int TPR = T / 32, PP = 32 / TPR;   // threads per window row, pixels per thread (256 -> 8 x 4, 64 -> 2 x 16)
     const int tid = threadIdx.x;
-    const int r = tid / TPR, c0 = (tid % TPR) * PP;
+    // 32 consecutive lanes = the 32 window rows of one column group: their LDS rows differ, and with the odd dword strides of sJ (17)
+    // and sD (33) they fall into 32 different banks (the sums are exact integers, so the pixel-to-lane assignment is free)
+    const int r = tid & 31, c0 = (tid >> 5) * PP;
     const int W = LK_WIN;
     const float half = 15.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
@@ -194,24 +213,40 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             ((uint32_t*)(sI + y * SI_STRIDE))[xw] = *(const uint32_t*)(Iorg + (ptrdiff_t)(ipy - 1 + y) * ls + ax0 + 4 * xw);
         }
         __syncthreads();
-        const uint8_t* sIo = sI + aoff;   // tile origin (ipx-1, ipy-1)
+        // (tile origin (ipx-1, ipy-1) = byte aoff of row 0)
         LSTAMP(1);
-        // ---- Scharr (calcSharrDeriv) at the 33x33 sample positions; constant 0 outside the image
-        for (int idx = tid; idx < 33 * 33; idx += T) {
-            const int y = idx / 33, x = idx - y * 33;
-            const uint8_t* c = &sIo[(y + 1) * SI_STRIDE + (x + 1)];
-            const int gx = ipx + x, gy = ipy + y;
-            short2 d = make_short2(0, 0);
-            if (gx >= 0 && gx < lw && gy >= 0 && gy < lh) {
-                const int t0m = (c[-SI_STRIDE - 1] + c[SI_STRIDE - 1]) * 3 + c[-1] * 10;
-                const int t0p = (c[-SI_STRIDE + 1] + c[SI_STRIDE + 1]) * 3 + c[1] * 10;
-                const int t1m = c[SI_STRIDE - 1] - c[-SI_STRIDE - 1];
-                const int t1c = c[SI_STRIDE] - c[-SI_STRIDE];
-                const int t1p = c[SI_STRIDE + 1] - c[-SI_STRIDE + 1];
-                d.x = (short)(t0p - t0m);
-                d.y = (short)((t1p + t1m) * 3 + t1c * 10);
+        // ---- Scharr (calcSharrDeriv) at the 33x33 sample positions; constant 0 outside the image. Task = (row y, run of SEG columns):
+        // three rows of SEG + 2 tile bytes through aligned dword loads, then the 3x3 stencil slides along the run in registers.
+        {
+            constexpr int SEG = (T >= 256) ? 5 : 11, NSEG = (33 + SEG - 1) / SEG;
+            for (int idx = tid; idx < 33 * NSEG; idx += T) {
+                const int sg = idx / 33, y = idx - sg * 33, x0 = sg * SEG;
+                uint32_t ra[(SEG + 2 + 3) / 4], rb[(SEG + 2 + 3) / 4], rc[(SEG + 2 + 3) / 4];
+                lds_row_bytes<SEG + 2>(sI + y * SI_STRIDE, aoff + x0, ra);
+                lds_row_bytes<SEG + 2>(sI + (y + 1) * SI_STRIDE, aoff + x0, rb);
+                lds_row_bytes<SEG + 2>(sI + (y + 2) * SI_STRIDE, aoff + x0, rc);
+                const int gy = ipy + y;
+                const bool row_in = gy >= 0 && gy < lh;
+#pragma unroll
+                for (int k = 0; k < SEG; k++) {
+                    const int x = x0 + k;
+                    if (x < 33) {
+                        const int a0 = PACKED_BYTE(ra, k), a1 = PACKED_BYTE(ra, k + 1), a2 = PACKED_BYTE(ra, k + 2);
+                        const int b0 = PACKED_BYTE(rb, k), b2 = PACKED_BYTE(rb, k + 2);
+                        const int c0_ = PACKED_BYTE(rc, k), c1 = PACKED_BYTE(rc, k + 1), c2 = PACKED_BYTE(rc, k + 2);
+                        const int gx = ipx + x;
+                        short2 d = make_short2(0, 0);
+                        if (row_in && gx >= 0 && gx < lw) {
+                            const int t0m = (a0 + c0_) * 3 + b0 * 10;
+                            const int t0p = (a2 + c2) * 3 + b2 * 10;
+                            const int t1m = c0_ - a0, t1c = c1 - a1, t1p = c2 - a2;
+                            d.x = (short)(t0p - t0m);
+                            d.y = (short)((t1p + t1m) * 3 + t1c * 10);
+                        }
+                        sD[y * SD_STRIDE + x] = d;
+                    }
+                }
             }
-            sD[y * SD_STRIDE + x] = d;
         }
         __syncthreads();
         LSTAMP(2);
@@ -219,13 +254,15 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
         int Iv[PP], Ix[PP], Iy[PP];
         int apart[3] = {0, 0, 0};
         {
-            const uint8_t* i0 = &sIo[(r + 1) * SI_STRIDE + (c0 + 1)];
+            uint32_t ia[(PP + 1 + 3) / 4], ib[(PP + 1 + 3) / 4];
+            lds_row_bytes<PP + 1>(sI + (r + 1) * SI_STRIDE, aoff + c0 + 1, ia);
+            lds_row_bytes<PP + 1>(sI + (r + 2) * SI_STRIDE, aoff + c0 + 1, ib);
             const short2* d0 = &sD[r * SD_STRIDE + c0];
-            int p0 = i0[0], p1 = i0[SI_STRIDE];
+            int p0 = PACKED_BYTE(ia, 0), p1 = PACKED_BYTE(ib, 0);
             short2 q0 = d0[0], q1 = d0[SD_STRIDE];
 #pragma unroll
             for (int k = 0; k < PP; k++) {
-                const int p0n = i0[k + 1], p1n = i0[SI_STRIDE + k + 1];
+                const int p0n = PACKED_BYTE(ia, k + 1), p1n = PACKED_BYTE(ib, k + 1);
                 const short2 q0n = d0[k + 1], q1n = d0[SD_STRIDE + k + 1];
                 // every factor fits 24 bits (pixels 8, weights 15, derivatives 13): v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter
                 Iv[k] = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9);
@@ -272,11 +309,13 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             bilinear_weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
             int bpart[2] = {0, 0};
             {
-                const uint8_t* j0 = &sJ[(wy + r) * SJ_STRIDE + wx + c0];
-                int p0 = j0[0], p1 = j0[SJ_STRIDE];
+                uint32_t ja[(PP + 1 + 3) / 4], jb[(PP + 1 + 3) / 4];
+                lds_row_bytes<PP + 1>(sJ + (wy + r) * SJ_STRIDE, wx + c0, ja);
+                lds_row_bytes<PP + 1>(sJ + (wy + r + 1) * SJ_STRIDE, wx + c0, jb);
+                int p0 = PACKED_BYTE(ja, 0), p1 = PACKED_BYTE(jb, 0);
 #pragma unroll
                 for (int k = 0; k < PP; k++) {
-                    const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
+                    const int p0n = PACKED_BYTE(ja, k + 1), p1n = PACKED_BYTE(jb, k + 1);
                     const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
                     bpart[0] += __mul24(diff, Ix[k]); bpart[1] += __mul24(diff, Iy[k]);
                     p0 = p0n; p1 = p1n;
@@ -319,11 +358,13 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 }
                 bilinear_weights(fx - inx, fy - iny, iw00, iw01, iw10, iw11);
                 int epart[1] = {0};
-                const uint8_t* j0 = &sJ[(wy + r) * SJ_STRIDE + wx + c0];
-                int p0 = j0[0], p1 = j0[SJ_STRIDE];
+                uint32_t ja[(PP + 1 + 3) / 4], jb[(PP + 1 + 3) / 4];
+                lds_row_bytes<PP + 1>(sJ + (wy + r) * SJ_STRIDE, wx + c0, ja);
+                lds_row_bytes<PP + 1>(sJ + (wy + r + 1) * SJ_STRIDE, wx + c0, jb);
+                int p0 = PACKED_BYTE(ja, 0), p1 = PACKED_BYTE(jb, 0);
 #pragma unroll
                 for (int k = 0; k < PP; k++) {
-                    const int p0n = j0[k + 1], p1n = j0[SJ_STRIDE + k + 1];
+                    const int p0n = PACKED_BYTE(ja, k + 1), p1n = PACKED_BYTE(jb, k + 1);
                     const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
                     epart[0] += diff < 0 ? -diff : diff;
                     p0 = p0n; p1 = p1n;
@@ -365,14 +406,19 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
 // launch. seqs[q] = byte offsets of the prev / next frame slots of sequence q inside `slots`; blocks[b] = (q, track) with track
 // indexing the concatenated coordinate / result arrays (-1 = padding block). All sequences share the frame geometry L.
 constexpr int LKB_T = 64;   // one wavefront per track: throughput form (see block_sum_exact)
-__global__ __launch_bounds__(LKB_T) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
-                                                   PyrLayout L, const float* __restrict__ prev_xy, LKParams P, float* __restrict__ out_xy,
+__global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
+                                                   int n_blocks, PyrLayout L, const float* __restrict__ prev_xy, LKParams P, float* __restrict__ out_xy,
                                                    uint8_t* __restrict__ out_status, float* __restrict__ out_err) {
-    const int2 bt = blocks[blockIdx.x];
-    if (bt.y < 0) return;
-    const LKSeq sq = seqs[bt.x];
-    const LKResult r = lk_track_block<LKB_T>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, false);
-    lk_store(r, bt.y, P, out_xy, out_status, out_err);
+    // grid-stride over the track list: the launcher may cap the grid (PMV_LK_BATCH_BLOCKS) so that the tracks of a round do not occupy
+    // every register-file slot of the chip while the short launches of the back-end chains wait for one
+    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int2 bt = blocks[b];
+        if (bt.y < 0) continue;
+        const LKSeq sq = seqs[bt.x];
+        const LKResult r = lk_track_block<LKB_T>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, false);
+        lk_store(r, bt.y, P, out_xy, out_status, out_err);
+        __syncthreads();
+    }
 }
 
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
@@ -390,8 +436,9 @@ hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_s
                            const float* d_prev_xy, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err) {
     if (n_blocks <= 0) return hipSuccess;
     if (!slots || !d_seqs || !d_blocks || !d_prev_xy || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
+    static const int cap = getenv("PMV_LK_BATCH_BLOCKS") ? atoi(getenv("PMV_LK_BATCH_BLOCKS")) : 0;
     ProfScope ps(K_LK, s);
-    hipLaunchKernelGGL(k_lk_batch, dim3(n_blocks), dim3(LKB_T), 0, s, slots, d_seqs, d_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err);
+    hipLaunchKernelGGL(k_lk_batch, dim3(cap > 0 && cap < n_blocks ? cap : n_blocks), dim3(LKB_T), 0, s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err);
     return hipGetLastError();
 }
 

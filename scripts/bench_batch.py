@@ -21,7 +21,7 @@ for b in range(Bmax):
 ref = None
 THREADED = int(os.environ.get("THREADED", "1"))
 DEVFP = int(os.environ.get("DEVFP", "0"))
-print("wait mode", os.environ.get("PMV_BATCH_WAIT", "block"), "threaded", THREADED, flush=True)
+print("wait mode", os.environ.get("PMV_BATCH_WAIT", "flag"), "threaded", THREADED, flush=True)
 for B in Bs:
     seqs = [(b * n, n, gt) for b in range(B)]
     r = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED, device_fivepoint=DEVFP)   # warm-up
