@@ -572,6 +572,17 @@ __device__ __forceinline__ void pnp_select_refit_body(const float* __restrict__ 
     if (tid == 0) { sh.lambdaLg10 = -3; sh.iters = 0; sh.done = 0; sh.state = 0; }
     __syncthreads();
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    // this thread's first two inliers stay in registers for all LM passes (n <= 512 is the rule: no pass waits for the index -> point
+    // chain of global loads again); further ones are re-read per pass. Same values, same accumulation order.
+    constexpr int RF_KEEP = 2;
+    double keepX[RF_KEEP][3], keepU[RF_KEEP][2];
+#pragma unroll
+    for (int q = 0; q < RF_KEEP; q++) {
+        const int e = tid + q * RF_T;
+        const int i = e < n ? inliers[e] : 0;
+        keepX[q][0] = (double)obj[3 * i]; keepX[q][1] = (double)obj[3 * i + 1]; keepX[q][2] = (double)obj[3 * i + 2];
+        keepU[q][0] = (double)img[2 * i]; keepU[q][1] = (double)img[2 * i + 1];
+    }
     // state 0: compute J & err at param, step; state 1: check err at new param
     t_lm0 = __builtin_readcyclecounter();
     for (;;) {
@@ -584,15 +595,21 @@ __device__ __forceinline__ void pnp_select_refit_body(const float* __restrict__ 
         for (int k = 0; k < 28; k++) acc[k] = 0;
         const double p0 = sh.param[0], p1 = sh.param[1], p2 = sh.param[2], p3 = sh.param[3], p4 = sh.param[4], p5 = sh.param[5];
         const double pa[3] = {p0, p1, p2};
-        for (int e = tid; e < n; e += RF_T) {
-            const int i = inliers[e];
-            const double X[3] = {(double)obj[3 * i], (double)obj[3 * i + 1], (double)obj[3 * i + 2]};
+        for (int e = tid, q = 0; e < n; e += RF_T, q++) {
+            double X[3], U[2];
+            if (q == 0) { X[0] = keepX[0][0]; X[1] = keepX[0][1]; X[2] = keepX[0][2]; U[0] = keepU[0][0]; U[1] = keepU[0][1]; }
+            else if (q == 1) { X[0] = keepX[1][0]; X[1] = keepX[1][1]; X[2] = keepX[1][2]; U[0] = keepU[1][0]; U[1] = keepU[1][1]; }
+            else {
+                const int i = inliers[e];
+                X[0] = (double)obj[3 * i]; X[1] = (double)obj[3 * i + 1]; X[2] = (double)obj[3 * i + 2];
+                U[0] = (double)img[2 * i]; U[1] = (double)img[2 * i + 1];
+            }
             double Xc[3], dpdw[9];
             d_angle_axis_rotate_jac(pa, X, Xc, jac ? dpdw : nullptr);
             Xc[0] += p3; Xc[1] += p4; Xc[2] += p5;
             const double z = Xc[2] ? 1. / Xc[2] : 1;
             const double x = Xc[0] * z, y = Xc[1] * z;
-            const double ex = x * fx + cx - (double)img[2 * i], ey = y * fy + cy - (double)img[2 * i + 1];
+            const double ex = x * fx + cx - U[0], ey = y * fy + cy - U[1];
             acc[27] += ex * ex + ey * ey;
             if (jac) {
                 double Ju[6], Jv[6];
