@@ -12,65 +12,186 @@ namespace pmv {
 // =========================================================================================================
 // Pyramid
 // =========================================================================================================
-// level 0: tight gray frame -> padded REFLECT_101 buffer. One thread writes 4 horizontally adjacent bytes.
-__global__ __launch_bounds__(256) void k_pad_level0(uint8_t* slots, PyrLayout L, int first_slot) {
-    uint8_t* slot = slots + (size_t)(first_slot + blockIdx.z) * L.slot_bytes;
-    const uint8_t* src = slot + L.gray_off;
-    const int w = L.w[0], h = L.h[0], stride = L.stride[0];
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;   // padded x
-    const int py = blockIdx.y;                              // padded y
-    if (x4 >= w + 2 * PAD) return;
-    const int sy = reflect101(py - PAD, h);
-    uint32_t v = 0;
+// Both kernels work on ONE padded output row per workgroup (grid = (1, padded rows, frames)) and touch global memory only with
+// coalesced dword / 16-byte accesses; the byte-granular REFLECT_101 gather happens in LDS. (The first version read 25 bytes per
+// output pixel straight from global memory: 0.6 TB/s; this one moves each source row once per output row that needs it.)
+
+// NB valid bytes starting at byte `off` of a 4-byte-aligned LDS row as packed little-endian dwords (see k_lk)
+template <int NB>
+__device__ inline void lds_bytes_aligned(const uint8_t* row, int off, uint32_t (&e)[(NB + 3) / 4]) {
+    constexpr int ND = (NB + 3 + 3) / 4, NE = (NB + 3) / 4;
+    const uint32_t* w = (const uint32_t*)row + (off >> 2);
+    const uint32_t sh = (uint32_t)off & 3u;
+    uint32_t d[ND];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int sx = reflect101(x4 + k - PAD, w);
-        v |= (uint32_t)src[(size_t)sy * w + sx] << (8 * k);
-    }
-    *(uint32_t*)(slot + L.off[0] + (size_t)py * stride + x4) = v;
+    for (int j = 0; j < ND; j++) d[j] = w[j];
+#pragma unroll
+    for (int j = 0; j < NE; j++) e[j] = __builtin_amdgcn_alignbyte(j + 1 < ND ? d[j + 1] : 0u, d[j], sh);
 }
 
-// level l-1 (padded) -> level l (padded): cv::pyrDown [1 4 6 4 1]^2, (sum+128)>>8; padding pixels are computed
-// directly as the pyrDown value at the REFLECT_101-mapped coordinate, so one pass writes interior and border.
-__global__ __launch_bounds__(256) void k_pyrdown(uint8_t* slots, PyrLayout L, int ld, int first_slot) {
+// One padded REFLECT_101 row from an unpadded row of `w` bytes that sits in LDS at byte `lead` of a 4-byte-aligned buffer (with >= 24
+// bytes of slack behind it): 16 bytes per thread and step. Interior groups are aligned gathers; the left and right borders are
+// byte-reversed runs of the row (PAD % 16 == 0, so only the group that straddles the right edge mixes both). Rows narrower than
+// PAD + 48 take the per-byte path everywhere.
+template <int T>
+__device__ inline void write_padded_row(const uint8_t* lrow, int lead, int w, uint8_t* dst) {
+    const int pw = w + 2 * PAD;
+    const bool wide = w >= PAD + 48;   // block-uniform
+    for (int x16 = threadIdx.x * 16; x16 < pw; x16 += T * 16) {   // (strides are multiples of 64: a 16-byte store never leaves the row)
+        uint32_t v[4];
+        const int sx0 = x16 - PAD;
+        if (sx0 >= 0 && sx0 + 15 < w) {
+            lds_bytes_aligned<16>(lrow, lead + sx0, v);
+        } else if (wide && (sx0 < 0 || sx0 >= w)) {
+            // dst[x16 + k] = row[s - k]: left border s = PAD - x16 (>= 16), right border s = 2w - 2 - sx0
+            const int s = sx0 < 0 ? -sx0 : 2 * w - 2 - sx0;
+            uint32_t e[4];
+            lds_bytes_aligned<16>(lrow, lead + s - 15, e);
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = __builtin_bswap32(e[3 - q]);
+        } else if (wide) {
+            // the group that straddles the right edge: the first n_in bytes run forward, the rest is the reversed run
+            const int n_in = w - sx0;   // 1 .. 15
+            uint32_t a[4], e[4];
+            lds_bytes_aligned<16>(lrow, lead + sx0, a);
+            lds_bytes_aligned<16>(lrow, lead + 2 * w - 2 - sx0 - 15, e);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int lo = n_in - 4 * q;
+                const uint32_t m = lo >= 4 ? 0xffffffffu : (lo <= 0 ? 0u : ((1u << (8 * lo)) - 1u));
+                v[q] = (a[q] & m) | (__builtin_bswap32(e[3 - q]) & ~m);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t t = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) t |= (uint32_t)lrow[lead + reflect101(sx0 + 4 * q + k, w)] << (8 * k);
+                v[q] = t;
+            }
+        }
+        *(uint4*)(dst + x16) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// level 0: tight gray frame -> padded REFLECT_101 buffer. The source row (tight, so generally unaligned) is fetched as the aligned
+// dwords that cover it.
+constexpr int PAD0_T = 128, PAD0_R = 4;   // rows per workgroup: their loads are in flight together
+__host__ __device__ inline int pad0_row_lds(int w) { return ((w + 3 + 24 + 3) / 4) * 4; }
+__global__ __launch_bounds__(PAD0_T) void k_pad_level0(uint8_t* slots, PyrLayout L, int first_slot) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t srow_all[];   // PAD0_R x row_lds bytes
+    uint8_t* slot = slots + (size_t)(first_slot + blockIdx.z) * L.slot_bytes;
+    const int w = L.w[0], h = L.h[0], stride = L.stride[0];
+    const int row_lds = pad0_row_lds(w);
+    const int ph = h + 2 * PAD;
+    const int py0 = blockIdx.y * PAD0_R;
+    unsigned lead[PAD0_R];
+#pragma unroll
+    for (int r = 0; r < PAD0_R; r++) {
+        const int py = py0 + r < ph ? py0 + r : ph - 1;     // (rows past the end repeat the last one; they are not stored)
+        const int sy = reflect101(py - PAD, h);
+        const unsigned b = (unsigned)sy * (unsigned)w;      // byte offset of the source row inside the gray block (gray_off % 64 == 0)
+        const unsigned a0 = b & ~3u;
+        lead[r] = b & 3u;
+        const uint32_t* src = (const uint32_t*)(slot + L.gray_off + a0);
+        const int nd = (int)((lead[r] + (unsigned)w + 3u) >> 2);   // dwords that contain a byte of the row: all inside the gray block
+        uint32_t* srow = (uint32_t*)(srow_all + r * row_lds);
+        for (int d = threadIdx.x; d < nd; d += PAD0_T) srow[d] = src[d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PAD0_R; r++) {
+        if (py0 + r >= ph) break;
+        write_padded_row<PAD0_T>(srow_all + r * row_lds, (int)lead[r], w, slot + L.off[0] + (size_t)(py0 + r) * stride);
+    }
+}
+
+// level l-1 (padded) -> level l (padded): cv::pyrDown [1 4 6 4 1]^2, (sum+128)>>8. A workgroup produces PYR_R padded output rows: per
+// row the vertical taps straight from coalesced dword loads of the five source rows (source columns -4 .. 2*dw+3: the level origin
+// is 4-byte aligned) as packed 16-bit sums into LDS, then the horizontal taps of the dw INTERIOR pixels in packed 16-bit arithmetic
+// (every intermediate <= 16 * 4080 + 128 < 2^16), then the padded row as mirrored runs of that interior row (the pyrDown value at a
+// REFLECT_101-mapped destination coordinate IS the interior pixel at that coordinate). Integer sums: the order does not matter.
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+__device__ inline pk_u16 as_pk(uint32_t x) { union { uint32_t u; pk_u16 p; } c; c.u = x; return c.p; }
+__device__ inline uint32_t as_u32(pk_u16 x) { union { uint32_t u; pk_u16 p; } c; c.p = x; return c.u; }
+constexpr int PYR_T = 256, PYR_R = 4;   // output rows per workgroup
+__host__ __device__ inline int pyr_vs_row(int dw) { return (2 * dw + 24 + 3) & ~3; }        // uint16 entries
+__host__ __device__ inline int pyr_out_row(int dw) { return ((dw + 3 + 24 + 3) / 4) * 4; }  // bytes
+__global__ __launch_bounds__(PYR_T) void k_pyrdown(uint8_t* slots, PyrLayout L, int ld, int first_slot) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
     uint8_t* slot = slots + (size_t)(first_slot + blockIdx.z) * L.slot_bytes;
     const int ls = ld - 1;
     const uint8_t* src = level_origin((const uint8_t*)slot, L, ls);
     const int ss = L.stride[ls];
     const int dw = L.w[ld], dh = L.h[ld], ds = L.stride[ld];
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int py = blockIdx.y;
-    if (x4 >= dw + 2 * PAD) return;
-    const int ry = reflect101(py - PAD, dh);
-    uint32_t v = 0;
+    const int ph = dh + 2 * PAD;
+    const int py0 = blockIdx.y * PYR_R;
+    const int nd = (2 * dw + 8) >> 2;
+    const int vs_row = pyr_vs_row(dw), out_row = pyr_out_row(dw);
+    uint8_t* orow_all = pyr_lds + (size_t)PYR_R * vs_row * 2;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int rx = reflect101(x4 + k - PAD, dw);
-        const uint8_t* p = src + (size_t)(2 * ry - 2) * ss + (2 * rx - 2);
-        int acc = 0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            const int ki = (i == 0 || i == 4) ? 1 : ((i == 2) ? 6 : 4);
-            const uint8_t* r = p + (size_t)i * ss;
-            acc += ki * (r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2]);
+    for (int r = 0; r < PYR_R; r++) {
+        const int py = py0 + r < ph ? py0 + r : ph - 1;
+        const int ry = reflect101(py - PAD, dh);
+        const uint8_t* r0 = src + (ptrdiff_t)(2 * ry - 2) * ss - 4;
+        uint16_t* vs = (uint16_t*)pyr_lds + r * vs_row;      // vs[c + 4] = vertical sum of source column c
+        for (int d = threadIdx.x; d < nd; d += PYR_T) {
+            const uint32_t a = *(const uint32_t*)(r0 + 4 * d), b = *(const uint32_t*)(r0 + ss + 4 * d), c = *(const uint32_t*)(r0 + 2 * ss + 4 * d),
+                           e = *(const uint32_t*)(r0 + 3 * ss + 4 * d), f = *(const uint32_t*)(r0 + 4 * ss + 4 * d);
+            // bytes 0,2 and bytes 1,3 of each row as 16-bit pairs; (a + f) + 4 (b + e) + 6 c <= 4080
+            const uint32_t M = 0x00ff00ffu;
+            const pk_u16 lo = (as_pk(a & M) + as_pk(f & M)) + (pk_u16)(4) * (as_pk(b & M) + as_pk(e & M)) + (pk_u16)(6) * as_pk(c & M);
+            const pk_u16 hi = (as_pk((a >> 8) & M) + as_pk((f >> 8) & M)) + (pk_u16)(4) * (as_pk((b >> 8) & M) + as_pk((e >> 8) & M)) + (pk_u16)(6) * as_pk((c >> 8) & M);
+            const uint32_t l = as_u32(lo), hh = as_u32(hi);   // l = (col0, col2), hh = (col1, col3)
+            *(uint2*)(vs + 4 * d) = make_uint2((l & 0xffffu) | (hh << 16), (l >> 16) | (hh & 0xffff0000u));
         }
-        v |= (uint32_t)((acc + 128) >> 8) << (8 * k);
     }
-    *(uint32_t*)(slot + L.off[ld] + (size_t)py * ds + x4) = v;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PYR_R; r++) {
+        // D[j] = (E[j], O[j]) = vertical sums of source columns 2j, 2j+1 = dword j + 2 of the row; output pixel i:
+        // E[i-1] + E[i+1] + 4 (O[i-1] + O[i]) + 6 E[i]
+        const uint32_t* vsd = (const uint32_t*)((const uint16_t*)pyr_lds + r * vs_row) + 2;
+        uint32_t* orow = (uint32_t*)(orow_all + r * out_row);
+        for (int i = threadIdx.x * 4; i < dw; i += PYR_T * 4) {
+            uint32_t D[7];
+#pragma unroll
+            for (int q = 0; q < 7; q++) D[q] = vsd[i - 1 + q];   // D[q] = pair i - 1 + q
+            uint32_t res[2];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int o = 2 * half;   // outputs i + o, i + o + 1
+                const pk_u16 Em = as_pk(__builtin_amdgcn_perm(D[o + 1], D[o], 0x05040100u)), E0 = as_pk(__builtin_amdgcn_perm(D[o + 2], D[o + 1], 0x05040100u)),
+                             Ep = as_pk(__builtin_amdgcn_perm(D[o + 3], D[o + 2], 0x05040100u));
+                const pk_u16 Om = as_pk(__builtin_amdgcn_perm(D[o + 1], D[o], 0x07060302u)), O0 = as_pk(__builtin_amdgcn_perm(D[o + 2], D[o + 1], 0x07060302u));
+                const pk_u16 t = ((Em + Ep) + (pk_u16)(4) * (Om + O0) + (pk_u16)(6) * E0 + (pk_u16)(128)) >> (pk_u16)(8);
+                res[half] = as_u32(t);   // two bytes in the 16-bit lanes
+            }
+            orow[i >> 2] = (res[0] & 0xffu) | ((res[0] >> 8) & 0xff00u) | ((res[1] & 0xffu) << 16) | ((res[1] & 0xff0000u) << 8);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PYR_R; r++) {
+        if (py0 + r >= ph) break;
+        write_padded_row<PYR_T>(orow_all + r * out_row, 0, dw, slot + L.off[ld] + (size_t)(py0 + r) * ds);
+    }
 }
 
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n) {
     if (!slots || n < 1 || first_slot < 0 || L.n_levels < 1) return hipErrorInvalidValue;
-    dim3 grid((L.w[0] + 2 * PAD + 1023) / 1024, L.h[0] + 2 * PAD, n);
+    dim3 grid(1, (L.h[0] + 2 * PAD + PAD0_R - 1) / PAD0_R, n);
+    const size_t shm = (size_t)pad0_row_lds(L.w[0]) * PAD0_R;
     ProfScope ps(K_PAD0, s);
-    hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, s, slots, L, first_slot);
+    hipLaunchKernelGGL(k_pad_level0, grid, dim3(PAD0_T), shm, s, slots, L, first_slot);
     return hipGetLastError();
 }
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int ld, int first_slot, int n) {
     if (!slots || n < 1 || first_slot < 0 || ld < 1 || ld >= L.n_levels) return hipErrorInvalidValue;
-    dim3 grid((L.w[ld] + 2 * PAD + 1023) / 1024, L.h[ld] + 2 * PAD, n);
+    dim3 grid(1, (L.h[ld] + 2 * PAD + PYR_R - 1) / PYR_R, n);
+    const size_t shm = ((size_t)pyr_vs_row(L.w[ld]) * 2 + (size_t)pyr_out_row(L.w[ld])) * PYR_R;
     ProfScope ps(K_PYRDOWN, s);
-    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, slots, L, ld, first_slot);
+    hipLaunchKernelGGL(k_pyrdown, grid, dim3(PYR_T), shm, s, slots, L, ld, first_slot);
     return hipGetLastError();
 }
 
