@@ -74,6 +74,10 @@ int pmv_frames_stream_end(pmv_ctx* ctx);
 /* Debug/parity: copy pyramid level `level` of `slot` (unpadded, tightly packed) back to host. Returns level dims. */
 int pmv_frame_get_level(pmv_ctx* ctx, int slot, int level, uint8_t* out, int* w, int* h);
 int pmv_frame_num_levels(pmv_ctx* ctx, int slot); /* maxLevel actually built (>=0) or <0 */
+/* Debug/parity: the same level WITH its 64-pixel BORDER_REFLECT_101 frame (what cv::buildOpticalFlowPyramid keeps around every level,
+ * lkpyramid.cpp, here PMV_PYR_PAD wide): (w + 128) x (h + 128) bytes, tightly packed; returns the padded dims. */
+#define PMV_PYR_PAD 64
+int pmv_frame_get_level_padded(pmv_ctx* ctx, int slot, int level, uint8_t* out, int* pw, int* ph);
 
 /* ---- feature extraction ------------------------------------------------------------------------ */
 /* cells: n_cells * 4 ints (x0, y0, w, h), each <= 255x255, sub-views of the frame in `slot`.

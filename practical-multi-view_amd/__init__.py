@@ -34,7 +34,7 @@ class BaSummary(C.Structure):
 # every symbol include/pmv_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
-    "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_num_levels",
+    "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_get_level_padded", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_detect_fast", "pmv_knn_match", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates", "pmv_fivepoint_hypotheses",
     "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
@@ -256,6 +256,13 @@ class Context:
         out = np.zeros(max_w * max_h, np.uint8)
         w, h = C.c_int(), C.c_int()
         self._ck(self.lib.pmv_frame_get_level(self.h, slot, level, _p(out, _u8p), C.byref(w), C.byref(h)))
+        return out[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    def get_level_padded(self, slot, level, max_w, max_h):
+        """the level with its 64-pixel BORDER_REFLECT_101 frame"""
+        out = np.zeros((max_w + 128) * (max_h + 128), np.uint8)
+        w, h = C.c_int(), C.c_int()
+        self._ck(self.lib.pmv_frame_get_level_padded(self.h, slot, level, _p(out, _u8p), C.byref(w), C.byref(h)))
         return out[: w.value * h.value].reshape(h.value, w.value).copy()
 
     # ---- BaseFeatureExtractor role ----

@@ -238,6 +238,22 @@ int pmv_frame_get_level(pmv_ctx* ctx, int slot, int level, uint8_t* out, int* w,
     return PMV_OK;
 }
 
+int pmv_frame_get_level_padded(pmv_ctx* ctx, int slot, int level, uint8_t* out, int* pw, int* ph) {
+    REQ(ctx && out, PMV_ERR_INVALID, "null argument");
+    REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "slot out of range");
+    const PyrLayout& L = ctx->slot_layout[slot];
+    REQ(L.n_levels > 0 && level >= 0 && level < L.n_levels, PMV_ERR_INVALID, "level %d not built for slot %d", level, slot);
+    static_assert(PAD == PMV_PYR_PAD, "header constant");
+    CKC(hipSetDevice(ctx->device));
+    CKC(hipStreamSynchronize(ctx->s_front));
+    const uint8_t* base = (const uint8_t*)ctx->d_slots + (size_t)slot * L.slot_bytes + L.off[level];
+    const int w = L.w[level] + 2 * PAD, h = L.h[level] + 2 * PAD;
+    CKC(hipMemcpy2D(out, w, base, L.stride[level], w, h, hipMemcpyDeviceToHost));
+    if (pw) *pw = w;
+    if (ph) *ph = h;
+    return PMV_OK;
+}
+
 int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy,
                  uint8_t* out_status, float* out_err) {
     REQ(ctx && (n == 0 || (prev_xy && out_xy && out_status && out_err)), PMV_ERR_INVALID, "pmv_lk_track: null argument");

@@ -30,6 +30,31 @@ def test_pyramid_matches_oracle(pmv, orc, gpu_ctx_factory, cfg):
     assert min(ref.shape) <= 32 or nl == 4
 
 
+@pytest.mark.parametrize("w,h", [(1241, 376), (1226, 370), (321, 163), (224, 131), (113, 97), (111, 80), (100, 66), (97, 67)])
+def test_pyramid_reflect101_frame(pmv, orc, gpu_ctx_factory, w, h):
+    """every level carries a 64-pixel BORDER_REFLECT_101 frame (cv::buildOpticalFlowPyramid pads each level; LK reads it for windows
+    that leave the image): the frame bytes equal numpy's reflect padding of the oracle's level, for widths on both sides of the kernels'
+    wide / narrow border paths (112) and for rows whose right edge falls on every position inside a 16-byte group"""
+    rng = np.random.default_rng(w * 1000 + h)
+    fr = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ctx = gpu_ctx_factory(w, h, n_slots=1)
+    ctx.frame_upload(0, fr)
+    ref = fr
+    for l in range(ctx.num_levels(0) + 1):
+        got = ctx.get_level_padded(0, l, w, h)
+        want = np.pad(ref, 64, mode="reflect") if min(ref.shape) > 64 else None
+        if want is None:   # numpy's reflect needs pad < size; build the REFLECT_101 index map by hand
+            def idx(n, size):
+                p = np.arange(-64, size + 64)
+                while ((p < 0) | (p >= size)).any():
+                    p = np.where(p < 0, -p, p); p = np.where(p >= size, 2 * size - 2 - p, p)
+                return p
+            want = ref[np.ix_(idx(64, ref.shape[0]), idx(64, ref.shape[1]))]
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), f"level {l}: {np.argwhere(got != want)[:5]}"
+        ref = orc.pyr_down(ref)
+
+
 def test_batched_build_equals_single_upload(pmv, gpu_ctx_factory):
     cfg = KITTI07
     fr = _frames(pmv, cfg, 3)
