@@ -265,6 +265,16 @@ __device__ inline void lds_row_bytes(const uint8_t* row, int off, uint32_t (&e)[
 }
 #define PACKED_BYTE(e, k) ((int)(((e)[(k) >> 2] >> (((k) & 3) * 8)) & 0xffu))
 
+// Bilinear sample as two packed dot products (v_dot2_i32_i16): the pixel of the upper row and the pixel of the lower row of one column
+// share a register as two 16-bit lanes, the weights of that column likewise: w00*p0 + w10*p1 is ONE instruction, the neighbouring
+// column adds w01*p0n + w11*p1n. Same integer as the four 24-bit products (|terms| < 2^28).
+typedef short pk_s16 __attribute__((ext_vector_type(2)));
+__device__ inline pk_s16 as_s16x2(uint32_t x) { union { uint32_t u; pk_s16 p; } c; c.u = x; return c.p; }
+__device__ inline uint32_t pack_weights(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+// column k of two packed byte rows -> (top | bottom << 16)
+#define PACKED_COLUMN(top, bot, k) __builtin_amdgcn_perm((bot)[(k) >> 2], (top)[(k) >> 2], 0x0c040c00u | ((uint32_t)((k) & 3) << 16) | (uint32_t)((k) & 3))
+__device__ inline int dot2_acc(uint32_t a, uint32_t w, int acc) { return __builtin_amdgcn_sdot2(as_s16x2(a), as_s16x2(w), acc, false); }
+
 // 64x64-byte search tile, dword copies (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0): 1024 dwords over T threads
 template <int T>
 __device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0, int ty0, int tid) {
@@ -348,21 +358,24 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 lds_row_bytes<SEG + 2>(sI + (y + 2) * SI_STRIDE, aoff + x0, rc);
                 const int gy = ipy + y;
                 const bool row_in = gy >= 0 && gy < lh;
+                // per tile column: the vertical smoothing 3*(a + c) + 10*b (for d/dx) and the vertical difference c - a (for d/dy) once,
+                // then dx = S[x+2] - S[x], dy = 3*(V[x] + V[x+2]) + 10*V[x+1]: the same integers as the 3x3 stencil per pixel
+                int S[SEG + 2], V[SEG + 2];
+#pragma unroll
+                for (int k = 0; k < SEG + 2; k++) {
+                    const int a = PACKED_BYTE(ra, k), b = PACKED_BYTE(rb, k), c = PACKED_BYTE(rc, k);
+                    S[k] = (a + c) * 3 + b * 10;
+                    V[k] = c - a;
+                }
 #pragma unroll
                 for (int k = 0; k < SEG; k++) {
                     const int x = x0 + k;
                     if (x < 33) {
-                        const int a0 = PACKED_BYTE(ra, k), a1 = PACKED_BYTE(ra, k + 1), a2 = PACKED_BYTE(ra, k + 2);
-                        const int b0 = PACKED_BYTE(rb, k), b2 = PACKED_BYTE(rb, k + 2);
-                        const int c0_ = PACKED_BYTE(rc, k), c1 = PACKED_BYTE(rc, k + 1), c2 = PACKED_BYTE(rc, k + 2);
                         const int gx = ipx + x;
                         short2 d = make_short2(0, 0);
                         if (row_in && gx >= 0 && gx < lw) {
-                            const int t0m = (a0 + c0_) * 3 + b0 * 10;
-                            const int t0p = (a2 + c2) * 3 + b2 * 10;
-                            const int t1m = c0_ - a0, t1c = c1 - a1, t1p = c2 - a2;
-                            d.x = (short)(t0p - t0m);
-                            d.y = (short)((t1p + t1m) * 3 + t1c * 10);
+                            d.x = (short)(S[k + 2] - S[k]);
+                            d.y = (short)((V[k + 2] + V[k]) * 3 + V[k + 1] * 10);
                         }
                         sD[y * SD_STRIDE + x] = d;
                     }
@@ -378,20 +391,25 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             uint32_t ia[(PP + 1 + 3) / 4], ib[(PP + 1 + 3) / 4];
             lds_row_bytes<PP + 1>(sI + (r + 1) * SI_STRIDE, aoff + c0 + 1, ia);
             lds_row_bytes<PP + 1>(sI + (r + 2) * SI_STRIDE, aoff + c0 + 1, ib);
-            const short2* d0 = &sD[r * SD_STRIDE + c0];
-            int p0 = PACKED_BYTE(ia, 0), p1 = PACKED_BYTE(ib, 0);
-            short2 q0 = d0[0], q1 = d0[SD_STRIDE];
+            const uint32_t* d0 = (const uint32_t*)&sD[r * SD_STRIDE + c0];   // (dx | dy << 16) per pixel
+            const uint32_t W0 = pack_weights(iw00, iw10), W1 = pack_weights(iw01, iw11);   // (upper, lower) weights of a column / of its right neighbour
+            uint32_t pc = PACKED_COLUMN(ia, ib, 0);
+            uint32_t q0 = d0[0], q1 = d0[SD_STRIDE];
+            uint32_t xc = __builtin_amdgcn_perm(q1, q0, 0x05040100u), yc = __builtin_amdgcn_perm(q1, q0, 0x07060302u);   // (upper.dx, lower.dx), (upper.dy, lower.dy)
 #pragma unroll
             for (int k = 0; k < PP; k++) {
-                const int p0n = PACKED_BYTE(ia, k + 1), p1n = PACKED_BYTE(ib, k + 1);
-                const short2 q0n = d0[k + 1], q1n = d0[SD_STRIDE + k + 1];
-                // every factor fits 24 bits (pixels 8, weights 15, derivatives 13): v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter
-                Iv[k] = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9);
-                const int ixv = descale(__mul24(q0.x, iw00) + __mul24(q0n.x, iw01) + __mul24(q1.x, iw10) + __mul24(q1n.x, iw11), 14);
-                const int iyv = descale(__mul24(q0.y, iw00) + __mul24(q0n.y, iw01) + __mul24(q1.y, iw10) + __mul24(q1n.y, iw11), 14);
+                const uint32_t pn = PACKED_COLUMN(ia, ib, k + 1);
+                const uint32_t q0n = d0[k + 1], q1n = d0[SD_STRIDE + k + 1];
+                const uint32_t xn = __builtin_amdgcn_perm(q1n, q0n, 0x05040100u), yn = __builtin_amdgcn_perm(q1n, q0n, 0x07060302u);
+                // kept as 256 - 512*I: the accumulator start of the search-side sample, so that (J_sum + 256 - 512*I) >> 9 = descale(J_sum, 9) - I
+                // needs neither the rounding constant nor the subtraction per pixel and iteration (512*I is a multiple of 2^9: exact)
+                Iv[k] = (1 << 8) - ((dot2_acc(pn, W1, dot2_acc(pc, W0, 1 << 8)) >> 9) << 9);
+                const int ixv = dot2_acc(xn, W1, dot2_acc(xc, W0, 1 << 13)) >> 14;
+                const int iyv = dot2_acc(yn, W1, dot2_acc(yc, W0, 1 << 13)) >> 14;
                 Ix[k] = ixv; Iy[k] = iyv;
+                // every factor fits 24 bits (derivatives 13): v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter
                 apart[0] += __mul24(ixv, ixv); apart[1] += __mul24(ixv, iyv); apart[2] += __mul24(iyv, iyv);
-                p0 = p0n; p1 = p1n; q0 = q0n; q1 = q1n;
+                pc = pn; xc = xn; yc = yn;
             }
         }
         double sA[3];
@@ -433,13 +451,14 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 uint32_t ja[(PP + 1 + 3) / 4], jb[(PP + 1 + 3) / 4];
                 lds_row_bytes<PP + 1>(sJ + (wy + r) * SJ_STRIDE, wx + c0, ja);
                 lds_row_bytes<PP + 1>(sJ + (wy + r + 1) * SJ_STRIDE, wx + c0, jb);
-                int p0 = PACKED_BYTE(ja, 0), p1 = PACKED_BYTE(jb, 0);
+                const uint32_t W0 = pack_weights(iw00, iw10), W1 = pack_weights(iw01, iw11);
+                uint32_t pc = PACKED_COLUMN(ja, jb, 0);
 #pragma unroll
                 for (int k = 0; k < PP; k++) {
-                    const int p0n = PACKED_BYTE(ja, k + 1), p1n = PACKED_BYTE(jb, k + 1);
-                    const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
+                    const uint32_t pn = PACKED_COLUMN(ja, jb, k + 1);
+                    const int diff = dot2_acc(pn, W1, dot2_acc(pc, W0, Iv[k])) >> 9;
                     bpart[0] += __mul24(diff, Ix[k]); bpart[1] += __mul24(diff, Iy[k]);
-                    p0 = p0n; p1 = p1n;
+                    pc = pn;
                 }
             }
             LSTAMP(10);
@@ -482,13 +501,14 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 uint32_t ja[(PP + 1 + 3) / 4], jb[(PP + 1 + 3) / 4];
                 lds_row_bytes<PP + 1>(sJ + (wy + r) * SJ_STRIDE, wx + c0, ja);
                 lds_row_bytes<PP + 1>(sJ + (wy + r + 1) * SJ_STRIDE, wx + c0, jb);
-                int p0 = PACKED_BYTE(ja, 0), p1 = PACKED_BYTE(jb, 0);
+                const uint32_t W0 = pack_weights(iw00, iw10), W1 = pack_weights(iw01, iw11);
+                uint32_t pc = PACKED_COLUMN(ja, jb, 0);
 #pragma unroll
                 for (int k = 0; k < PP; k++) {
-                    const int p0n = PACKED_BYTE(ja, k + 1), p1n = PACKED_BYTE(jb, k + 1);
-                    const int diff = descale(__mul24(p0, iw00) + __mul24(p0n, iw01) + __mul24(p1, iw10) + __mul24(p1n, iw11), 9) - Iv[k];
+                    const uint32_t pn = PACKED_COLUMN(ja, jb, k + 1);
+                    const int diff = dot2_acc(pn, W1, dot2_acc(pc, W0, Iv[k])) >> 9;
                     epart[0] += diff < 0 ? -diff : diff;
-                    p0 = p0n; p1 = p1n;
+                    pc = pn;
                 }
                 double sE[1];
                 block_sum_exact<1, T>(epart, sE, sred, slot); slot ^= 1;
