@@ -117,6 +117,7 @@ void* orc_pipeline_run(const vo::PipelineParams* P, const uint8_t* frames, const
     orc::ba_set_pool(ba_pool.get(), 4);
     auto* pnp = new CpuPnP(); pnp->tracker = &run->pipe;
     auto* tri = new vo::FivePointTri(); tri->tracker = &run->pipe; tri->workers = std::max(1, std::min(P->n_threads, 8));
+    tri->prefetch_threads = P->n_threads > 1 ? 2 : 0;   // same host code as the product: essential matrices ahead of time
     auto* ba = new CpuBA(); ba->tracker = &run->pipe;
     run->m = lk; run->p = pnp; run->tr = tri; run->b = ba;
     run->pipe.extractor = ex; run->pipe.matcher = lk; run->pipe.pnpsolver = pnp; run->pipe.triangulator = tri; run->pipe.ba = ba;

@@ -253,6 +253,7 @@ int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K
         auto* pnp = new HipPnP(); pnp->ctx = ctx; pnp->tracker = &run.pipe;
         auto* tri = new HipTri(); tri->ctx = ctx; tri->tracker = &run.pipe; tri->workers = std::max(1, P->n_threads);
         tri->use_hypothesis_hook = P->device_fivepoint != 0;
+        tri->prefetch_threads = (P->n_threads > 1 && !tri->use_hypothesis_hook) ? 2 : 0;   // only the two-thread pipeline calls prefetch()
         auto* ba = new HipBA(); ba->ctx = ctx; ba->tracker = &run.pipe;
         run.m = lk; run.p = pnp; run.tr = tri; run.b = ba;
         run.pipe.extractor = ex; run.pipe.matcher = lk; run.pipe.pnpsolver = pnp; run.pipe.triangulator = tri; run.pipe.ba = ba;

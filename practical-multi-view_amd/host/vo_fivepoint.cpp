@@ -572,12 +572,68 @@ void dlt_candidates_host(const double* q1, const double* q2, int n, const double
     }
 }
 
+// ---- findEssentialMat ahead of time (see vo_pipeline.h) ----------------------------------------------------------------
+void FivePointTri::prefetch(const Frame& prev) {
+    if (prefetch_threads <= 0 || use_hypothesis_hook) return;
+    auto job = std::make_shared<EssentialJob>();
+    job->frame = prev.frame;
+    job->p1.reserve(2 * prev.feat_corr.size()); job->p2.reserve(2 * prev.feat_corr.size());
+    for (auto& p : prev.feat_corr) {   // the loop of triangulate() (OpenCVFivePointTri.cpp:9-22), coordinates only
+        if (p.first.expired() || p.second.expired()) continue;
+        std::shared_ptr<Feature> fst = p.first.lock();
+        std::shared_ptr<Feature> sec = p.second.lock();
+        job->p1.push_back(fst->column); job->p1.push_back(fst->row);
+        job->p2.push_back(sec->column); job->p2.push_back(sec->row);
+    }
+    std::lock_guard<std::mutex> lk(pf_mu);
+    if (pf_threads.empty())
+        for (int i = 0; i < prefetch_threads; i++) pf_threads.emplace_back([this] { prefetch_worker(); });
+    pf_jobs[job->frame] = job;
+    pf_queue.push_back(std::move(job));
+    pf_cv.notify_one();
+}
+
+void FivePointTri::prefetch_worker() {
+    for (;;) {
+        std::shared_ptr<EssentialJob> job;
+        {
+            std::unique_lock<std::mutex> lk(pf_mu);
+            pf_cv.wait(lk, [&] { return pf_stop || !pf_queue.empty(); });
+            if (pf_stop) return;
+            job = std::move(pf_queue.front());
+            pf_queue.pop_front();
+        }
+        int expected = 0;
+        if (!job->state.compare_exchange_strong(expected, 1)) continue;   // the back-end got there first
+        job->ok = find_essential_mat(job->p1.data(), job->p2.data(), (int)(job->p1.size() / 2), tracker->camera, 0.99, 1.0, job->E, job->mask,
+                                     &job->drawn, nullptr, 1, nullptr);
+        job->state.store(2, std::memory_order_release);
+    }
+}
+
+FivePointTri::~FivePointTri() {
+    { std::lock_guard<std::mutex> lk(pf_mu); pf_stop = true; }
+    pf_cv.notify_all();
+    for (auto& t : pf_threads) t.join();
+}
+
 // ---- OpenCVFivePointTri.cpp:5-54 ---------------------------------------------------------------------------------
 void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
     const int j = src.frame;
     std::vector<double> p1, p2;
     std::vector<std::shared_ptr<Feature>> p1_ptr, p2_ptr;
-    if (workers > 1) {   // wake the helper threads now: they are spinning by the time the gather below is done
+    // a result (or a job) from the front-end's prefetch for this frame pair; older entries belong to frames that went through PnP
+    std::shared_ptr<EssentialJob> job;
+    if (prefetch_threads > 0) {
+        std::lock_guard<std::mutex> lk(pf_mu);
+        auto it = pf_jobs.find(j);
+        if (it != pf_jobs.end()) job = it->second;
+        for (auto k = pf_jobs.begin(); k != pf_jobs.end();) k = k->first <= j ? pf_jobs.erase(k) : std::next(k);
+    }
+    bool claimed = false;   // the job exists but no helper has started it: compute here, as without prefetch
+    if (job) { int expected = 0; claimed = job->state.compare_exchange_strong(expected, 1); }
+    const bool inline_e = !job || claimed;
+    if (inline_e && workers > 1) {   // wake the helper threads now: they are spinning by the time the gather below is done
         if (!pool) pool = std::make_shared<SpinPool>(workers - 1);
         pool->begin();
     }
@@ -601,9 +657,19 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     int drawn = 0;
     auto tE = std::chrono::steady_clock::now();
     HostCpuScope* cpu_e = new HostCpuScope(tracker->stats.hp.t[14]);
-    const bool ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn, pool.get(), workers, use_hypothesis_hook ? this : nullptr);
+    bool ok;
+    if (!inline_e && job->p1 == p1 && job->p2 == p2) {   // same correspondences in the same order (always, by construction)
+        while (job->state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+        ok = job->ok; drawn = job->drawn; mask = job->mask;
+        for (int i = 0; i < 9; i++) E[i] = job->E[i];
+        prefetch_hits++;
+    } else {
+        ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn, inline_e ? pool.get() : nullptr, inline_e ? workers : 1,
+                                use_hypothesis_hook ? this : nullptr);
+        prefetch_inline++;
+    }
     delete cpu_e;
-    if (pool) pool->end();
+    if (inline_e && pool) pool->end();
     tracker->stats.t_tri_essential += std::chrono::duration<double>(std::chrono::steady_clock::now() - tE).count();
     tracker->stats.tri_hypotheses += drawn;
     if (!ok) {

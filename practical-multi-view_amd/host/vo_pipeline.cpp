@@ -533,6 +533,7 @@ void OdometryPipeline::run_threaded() {
         const int n_corr = (int)feat_corr.size();
         prev->feat_corr = std::move(feat_corr);
         index_feat_corr(*prev);
+        if (triangulator) triangulator->prefetch(*prev);   // (prev, this frame) reaches the back-end one frame from now at the earliest
         if (n_corr < cfg.tracked_features_tol) {
             std::vector<GridSection> roi = getGridROI(*prev);
             const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());

@@ -6,6 +6,11 @@
 // virtual "kernel" hooks: the product implements them with the HIP C ABI (include/pmv_hip.h), the oracle with its CPU
 // restatement.  GUI, drawing, video, config parsing and the error file are out of scope.
 #pragma once
+#include <unordered_map>
+#include <thread>
+#include <deque>
+#include <condition_variable>
+#include <atomic>
 #include "vo_types.h"
 #include <functional>
 #include <chrono>
@@ -95,6 +100,13 @@ public:
     int workers = 1;                 // threads evaluating RANSAC hypotheses side by side (results do not depend on it)
     std::shared_ptr<SpinPool> pool;  // created on first use when workers > 1
     void triangulate(Frame& src, Frame& next, Mat3& R, Vec3& t) override;
+    // findEssentialMat ahead of time: E of a frame pair depends on the 2-D correspondences only (OpenCVFivePointTri.cpp:8-24), which
+    // the front-end has a frame before the back-end asks. With prefetch_threads > 0 the front-end hands each pair's points to
+    // that many helper threads; triangulate() takes the finished result (or claims the job and computes it itself when no helper
+    // has started it). Same function on the same points: identical E, mask and iteration count. Off for the hook form.
+    int prefetch_threads = 0;
+    void prefetch(const Frame& prev) override;
+    ~FivePointTri() override;
     // optional kernel hook for the RANSAC hypotheses of findEssentialMat: for n_hyp samples (5 indices each) of the n normalised
     // correspondences return the essential matrices of every sample (models: n_hyp x 90, n_models: n_hyp) and their inlier counts
     // under the float32 Sampson test (counts: n_hyp x 10). Return false (default) to evaluate them on host threads instead.
@@ -110,6 +122,24 @@ public:
                                 uint8_t* out_mask, int* out_good) {
         dlt_candidates_host(q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good);
     }
+    long prefetch_hits = 0, prefetch_inline = 0;   // triangulate() calls served by a helper / computed by the caller
+private:
+    struct EssentialJob {
+        int frame = 0;
+        std::vector<double> p1, p2;
+        double E[9] = {0};
+        std::vector<uint8_t> mask;
+        int drawn = 0;
+        bool ok = false;
+        std::atomic<int> state{0};   // 0 queued, 1 claimed (helper or caller), 2 done
+    };
+    std::mutex pf_mu;
+    std::condition_variable pf_cv;
+    std::deque<std::shared_ptr<EssentialJob>> pf_queue;
+    std::unordered_map<int, std::shared_ptr<EssentialJob>> pf_jobs;
+    std::vector<std::thread> pf_threads;
+    bool pf_stop = false;
+    void prefetch_worker();
 };
 class BundleAdjustmentBase : public BaseOptimizer {              // CeresBundleAdjustment
 public:

@@ -224,6 +224,10 @@ class BaseTriangulator {
 public:
     virtual ~BaseTriangulator() {}
     virtual void triangulate(Frame& src, Frame& next, Mat3& R, Vec3& t) = 0;   // BaseTriangulator.h:20
+    // Called by the front-end thread of the two-thread pipeline as soon as `prev.feat_corr` (the correspondences prev -> the frame
+    // just tracked) is final. A triangulator may start whatever depends on nothing but these correspondences; the back-end reaches
+    // this frame pair at least one frame later. Default: nothing.
+    virtual void prefetch(const Frame& prev) { (void)prev; }
 };
 class BaseOptimizer {
 public:
