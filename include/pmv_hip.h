@@ -168,6 +168,11 @@ int pmv_fivepoint_hypotheses(pmv_ctx* ctx, const double* q1, const double* q2, i
  * out_good: [4] number of points passing all tests. n <= max_tracks. */
 int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4,
                                const uint8_t* mask_in, double* out_Q, uint8_t* out_mask, int* out_good);
+/* The same call on an auxiliary lane of the context (own workspace and stream, created on first use, one call at a time): for a
+ * helper thread that evaluates cv::recoverPose of a frame pair AHEAD of the back-end thread (the candidates depend on the 2-D
+ * correspondences only), concurrently with pmv_pnp_ransac / pmv_ba_solve / pmv_triangulate_candidates on the main lane. */
+int pmv_triangulate_candidates_ahead(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,
+                                     double* out_Q, uint8_t* out_mask, int* out_good);
 
 /* ---- call log (parity tooling) -------------------------------------------------------------------------------------------
  * While recording is on, every pmv_pnp_ransac / pmv_ba_solve / pmv_triangulate_candidates call of this context (also those

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
     "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_get_level_padded", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_detect_fast", "pmv_knn_match", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
-    "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates", "pmv_fivepoint_hypotheses",
+    "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates", "pmv_triangulate_candidates_ahead", "pmv_fivepoint_hypotheses",
     "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
     "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_lk_counters", "pmv_prof_kernel_name", "pmv_prof_read",
     "pmv_pipeline_run", "pmv_pipeline_run_streamed", "pmv_pipeline_run_batch", "pmv_batch_stats", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",

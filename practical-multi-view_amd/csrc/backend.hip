@@ -87,7 +87,11 @@ void backend_free(BackendBuffers* b) {
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     delete b;
 }
-void backend_destroy(pmv_ctx* c) { backend_free(c->be); c->be = nullptr; }
+void backend_destroy(pmv_ctx* c) {
+    backend_free(c->be); c->be = nullptr;
+    if (c->be_ahead) { backend_free(c->be_ahead); c->be_ahead = nullptr; }
+    if (c->s_ahead) { (void)hipStreamSynchronize(c->s_ahead); (void)hipStreamDestroy(c->s_ahead); c->s_ahead = nullptr; }
+}
 
 // cv::RNG (multiply-with-carry) and RANSACPointSetRegistrator::getSubset (5 distinct indices)
 struct CvRNG {
@@ -565,14 +569,8 @@ int pmv_fivepoint_hypotheses(pmv_ctx* ctx, const double* q1, const double* q2, i
 }
 
 // the per-point part of cv::recoverPose (OpenCVFivePointTri.cpp:27): DLT triangulation + cheirality for the four candidates
-int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,
-                               double* out_Q, uint8_t* out_mask, int* out_good) {
-    REQ(ctx && q1 && q2 && P1x4 && mask_in && out_Q && out_mask && out_good, PMV_ERR_INVALID, "pmv_triangulate_candidates: null argument");
-    REQ(n >= 1 && n <= ctx->max_tracks, PMV_ERR_CAPACITY, "pmv_triangulate_candidates: n=%d (1..max_tracks=%d)", n, ctx->max_tracks);
-    tl_prof = &ctx->prof;
-    CKC(hipSetDevice(ctx->device));
-    BackendBuffers* b = ctx->be;
-    hipStream_t s = ctx->s_back;
+static int triangulate_on(pmv_ctx* ctx, BackendBuffers* b, hipStream_t s, const double* q1, const double* q2, int n, const double* P1x4,
+                          const uint8_t* mask_in, double* out_Q, uint8_t* out_mask, int* out_good) {
     DltProblem P;
     size_t in_bytes = 0;
     dlt_prepare(b, q1, q2, n, P1x4, mask_in, &P, &in_bytes);
@@ -581,6 +579,31 @@ int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2,
     CKC(hipStreamSynchronize(s));
     dlt_finish(ctx, b, q1, q2, n, P1x4, mask_in, in_bytes, out_Q, out_mask, out_good);
     return PMV_OK;
+}
+
+int pmv_triangulate_candidates(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,
+                               double* out_Q, uint8_t* out_mask, int* out_good) {
+    REQ(ctx && q1 && q2 && P1x4 && mask_in && out_Q && out_mask && out_good, PMV_ERR_INVALID, "pmv_triangulate_candidates: null argument");
+    REQ(n >= 1 && n <= ctx->max_tracks, PMV_ERR_CAPACITY, "pmv_triangulate_candidates: n=%d (1..max_tracks=%d)", n, ctx->max_tracks);
+    tl_prof = &ctx->prof;
+    CKC(hipSetDevice(ctx->device));
+    return triangulate_on(ctx, ctx->be, ctx->s_back, q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good);
+}
+
+int pmv_triangulate_candidates_ahead(pmv_ctx* ctx, const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in,
+                                     double* out_Q, uint8_t* out_mask, int* out_good) {
+    REQ(ctx && q1 && q2 && P1x4 && mask_in && out_Q && out_mask && out_good, PMV_ERR_INVALID, "pmv_triangulate_candidates_ahead: null argument");
+    REQ(n >= 1 && n <= ctx->max_tracks, PMV_ERR_CAPACITY, "pmv_triangulate_candidates_ahead: n=%d (1..max_tracks=%d)", n, ctx->max_tracks);
+    std::lock_guard<std::mutex> lk(ctx->ahead_mu);   // one call at a time on the auxiliary lane (its callers are helper threads)
+    CKC(hipSetDevice(ctx->device));
+    if (!ctx->be_ahead) {
+        BackendBuffers* b = nullptr;
+        const int rc = backend_alloc(ctx, &b);
+        if (rc != PMV_OK) { if (b) backend_free(b); return rc; }
+        ctx->be_ahead = b;
+        CKC(hipStreamCreateWithFlags(&ctx->s_ahead, hipStreamNonBlocking));
+    }
+    return triangulate_on(ctx, ctx->be_ahead, ctx->s_ahead, q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good);
 }
 
 }  // extern "C"

@@ -114,6 +114,10 @@ struct HipTri : vo::FivePointTri {   // five-point RANSAC hypotheses on host thr
                         uint8_t* out_mask, int* out_good) override {
         ck(ctx, pmv_triangulate_candidates(ctx, q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good));
     }
+    void dlt_candidates_ahead(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
+                              uint8_t* out_mask, int* out_good) override {
+        ck(ctx, pmv_triangulate_candidates_ahead(ctx, q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good));
+    }
 };
 struct HipBA : BundleAdjustmentBase {
     pmv_ctx* ctx;

@@ -52,6 +52,10 @@ struct pmv_ctx {
     int *h_det_xy = nullptr, *h_det_count = nullptr;
     double* h_det_score = nullptr;
     pmv::BackendBuffers* be = nullptr;
+    // second back-end lane (own workspace + stream) for work a helper thread runs ahead of the back-end: pmv_triangulate_candidates_ahead
+    pmv::BackendBuffers* be_ahead = nullptr;
+    hipStream_t s_ahead = nullptr;
+    std::mutex ahead_mu;
     pmv::BatchEngine* engine = nullptr; // created by the first pmv_pipeline_run_batch
     pmv::Ingest* ingest = nullptr;      // non-null while a pmv_frames_stream_begin .. _end bracket is open
     pmv::Profiler prof;

@@ -485,7 +485,7 @@ bool find_essential_mat(const double* p1, const double* p2, int n, const double*
 
 // cv::recoverPose(E, points1, points2, K, R, t, distanceThresh = HUGE_VAL, mask (in/out), triangulatedPoints 4xN)
 int recover_pose(FivePointTri* self, const double* E, const double* p1, const double* p2, int n, const double* K, double* R_out,
-                 double* t_out, std::vector<uint8_t>& mask, std::vector<double>& tri4) {
+                 double* t_out, std::vector<uint8_t>& mask, std::vector<double>& tri4, bool ahead) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     std::vector<double> q1(2 * n), q2(2 * n);
     for (int i = 0; i < n; i++) {
@@ -512,7 +512,8 @@ int recover_pose(FivePointTri* self, const double* E, const double* p1, const do
     std::vector<uint8_t> masks((size_t)4 * n);
     int good[4] = {0, 0, 0, 0};
     // the four (R, t) candidates (cv::recoverPose evaluates them one after another) go through the kernel hook
-    self->dlt_candidates(q1.data(), q2.data(), n, P1x4, mask.data(), Q.data(), masks.data(), good);
+    if (ahead) self->dlt_candidates_ahead(q1.data(), q2.data(), n, P1x4, mask.data(), Q.data(), masks.data(), good);
+    else self->dlt_candidates(q1.data(), q2.data(), n, P1x4, mask.data(), Q.data(), masks.data(), good);
     int sel;
     if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) sel = 0;
     else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) sel = 1;
@@ -605,8 +606,11 @@ void FivePointTri::prefetch_worker() {
         }
         int expected = 0;
         if (!job->state.compare_exchange_strong(expected, 1)) continue;   // the back-end got there first
-        job->ok = find_essential_mat(job->p1.data(), job->p2.data(), (int)(job->p1.size() / 2), tracker->camera, 0.99, 1.0, job->E, job->mask,
-                                     &job->drawn, nullptr, 1, nullptr);
+        try {
+            const int n = (int)(job->p1.size() / 2);
+            job->ok = find_essential_mat(job->p1.data(), job->p2.data(), n, tracker->camera, 0.99, 1.0, job->E, job->mask, &job->drawn, nullptr, 1, nullptr);
+            if (job->ok) recover_pose(this, job->E, job->p1.data(), job->p2.data(), n, tracker->camera, job->R, job->t, job->mask, job->tri, true);
+        } catch (...) { job->error = std::current_exception(); }
         job->state.store(2, std::memory_order_release);
     }
 }
@@ -657,11 +661,18 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     int drawn = 0;
     auto tE = std::chrono::steady_clock::now();
     HostCpuScope* cpu_e = new HostCpuScope(tracker->stats.hp.t[14]);
-    bool ok;
+    bool ok, have_pose = false;
     if (!inline_e && job->p1 == p1 && job->p2 == p2) {   // same correspondences in the same order (always, by construction)
         while (job->state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
-        ok = job->ok; drawn = job->drawn; mask = job->mask;
+        if (job->error) { delete cpu_e; std::rethrow_exception(job->error); }
+        ok = job->ok; drawn = job->drawn;
         for (int i = 0; i < 9; i++) E[i] = job->E[i];
+        if (ok) {   // recoverPose ran in the helper as well: R, unit t, the mask it updated, the homogeneous points
+            mask.swap(job->mask); tri.swap(job->tri);
+            for (int i = 0; i < 9; i++) R_out.m[i] = job->R[i];
+            for (int i = 0; i < 3; i++) t_out.v[i] = job->t[i];
+            have_pose = true;
+        }
         prefetch_hits++;
     } else {
         ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn, inline_e ? pool.get() : nullptr, inline_e ? workers : 1,
@@ -679,7 +690,7 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
         return;
     }
     auto tP = std::chrono::steady_clock::now();
-    recover_pose(this, E, p1.data(), p2.data(), n, tracker->camera, R_out.m, t_out.v, mask, tri);
+    if (!have_pose) recover_pose(this, E, p1.data(), p2.data(), n, tracker->camera, R_out.m, t_out.v, mask, tri);
     tracker->stats.t_tri_pose += std::chrono::duration<double>(std::chrono::steady_clock::now() - tP).count();
     const Vec3& g1 = tracker->gt_t[j + tracker->init_offset + 1];
     const Vec3& g0 = tracker->gt_t[j + tracker->init_offset];

@@ -6,6 +6,7 @@
 // virtual "kernel" hooks: the product implements them with the HIP C ABI (include/pmv_hip.h), the oracle with its CPU
 // restatement.  GUI, drawing, video, config parsing and the error file are out of scope.
 #pragma once
+#include <exception>
 #include <unordered_map>
 #include <thread>
 #include <deque>
@@ -122,6 +123,12 @@ public:
                                 uint8_t* out_mask, int* out_good) {
         dlt_candidates_host(q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good);
     }
+    // the same kernel hook when called from a prefetch helper thread, concurrently with the back-end thread's own plugin calls: a plugin
+    // whose dlt_candidates is not re-entrant overrides it (the HIP plugin: the context's auxiliary lane)
+    virtual void dlt_candidates_ahead(const double* q1, const double* q2, int n, const double* P1x4, const uint8_t* mask_in, double* out_Q,
+                                      uint8_t* out_mask, int* out_good) {
+        dlt_candidates_host(q1, q2, n, P1x4, mask_in, out_Q, out_mask, out_good);
+    }
     long prefetch_hits = 0, prefetch_inline = 0;   // triangulate() calls served by a helper / computed by the caller
 private:
     struct EssentialJob {
@@ -131,6 +138,10 @@ private:
         std::vector<uint8_t> mask;
         int drawn = 0;
         bool ok = false;
+        // cv::recoverPose of the pair (it needs E and the points only): rotation, unit translation, updated mask, triangulated points
+        double R[9] = {0}, t[3] = {0};
+        std::vector<double> tri;
+        std::exception_ptr error;    // a plugin error in the helper is rethrown by triangulate() on the back-end thread
         std::atomic<int> state{0};   // 0 queued, 1 claimed (helper or caller), 2 done
     };
     std::mutex pf_mu;
@@ -240,7 +251,7 @@ bool find_essential_mat(const double* p1, const double* p2, int n, const double*
                         std::vector<uint8_t>& mask, int* samples_drawn, SpinPool* pool, int pool_width, FivePointTri* hook = nullptr);
 // cv::recoverPose(E, points1, points2, K, R, t, HUGE_VAL, mask (in/out), triangulatedPoints): returns the number of good points
 int recover_pose(FivePointTri* self, const double* E, const double* p1, const double* p2, int n, const double* K, double* R_out,
-                 double* t_out, std::vector<uint8_t>& mask, std::vector<double>& tri4);
+                 double* t_out, std::vector<uint8_t>& mask, std::vector<double>& tri4, bool ahead = false);
 std::shared_ptr<SpinPool> make_spin_pool(int workers);
 
 // cv::Rodrigues both ways (host copy for the adapters)
