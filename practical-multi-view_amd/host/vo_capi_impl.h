@@ -44,6 +44,7 @@ inline void pipeline_setup(PipelineRun& run, const PipelineParams& P, const uint
     pl.cfg.ba_iterations = P.ba_iterations;
     pl.cfg.extractor = P.extractor;
     pl.cfg.stop = P.n_frames;
+    if (const char* e = getenv("PMV_PIPE_DEPTH")) pl.cfg.pipe_depth = atoi(e) > 0 ? atoi(e) : pl.cfg.pipe_depth;   // (a knob that changes no result)
     memcpy(pl.camera, K9, sizeof(double) * 9);
     pl.images.resize(P.n_frames);
     pl.gt_t.resize(P.n_frames);

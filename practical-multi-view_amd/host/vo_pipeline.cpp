@@ -486,9 +486,12 @@ void OdometryPipeline::run_threaded() {
     // entries j, j+1 <= k-1 that the front-end no longer reads; the vector itself is guarded by frames_mu, which
     // BundleAdjustmentBase::apply takes as well when it snapshots its window.
     std::mutex& mu = frames_mu;
-    std::condition_variable cv;
+    std::condition_variable cv, cv_space;
     std::deque<int> jobs;
     bool done = false;
+    // dlib::pipe<Job> job_pipe(605) in the reference (OdometryPipeline.cpp:26): the front-end blocks when that many jobs wait. The depth
+    // changes no result (the pipeline is schedule-deterministic); a short pipe keeps the frames the back-end is about to read in cache.
+    const size_t pipe_depth = (size_t)std::max(1, cfg.pipe_depth);
     // a plugin error (e.g. a capacity error of the device library) in either thread ends the run and is rethrown to the caller
     std::exception_ptr back_error;
     std::atomic<bool> failed{false};
@@ -504,12 +507,14 @@ void OdometryPipeline::run_threaded() {
                     if (jobs.empty()) return;
                     j = jobs.front(); jobs.pop_front();
                     a = frames[j]; b = frames[j + 1];
+                    cv_space.notify_one();
                 }
                 estimatePose(*a, *b);
             }
         } catch (...) {
             back_error = std::current_exception();
             failed.store(true);
+            cv_space.notify_all();
         }
     });
     std::exception_ptr front_error;
@@ -558,7 +563,10 @@ void OdometryPipeline::run_threaded() {
         {
             std::unique_lock<std::mutex> lk(mu);
             frames.push_back(std::move(stored));
-            if (frame_no >= 2) { jobs.push_back(frame_no - 2); cv.notify_one(); }
+            if (frame_no >= 2) {
+                cv_space.wait(lk, [&] { return jobs.size() < pipe_depth || failed.load(); });   // job_pipe.enqueue blocks on a full pipe
+                jobs.push_back(frame_no - 2); cv.notify_one();
+            }
         }
         if (on_frame_added) on_frame_added(frame_no);
     }

@@ -33,6 +33,7 @@ struct Config {   // the keys of the reference's config file that reach the hot 
     double gftt_quality = 0.01, gftt_min_distance = 5;   // OpenCVGoodFeatureExtractor.h:9,11
     int extractor = 0;        // 0 = OpenCVGoodFeatureExtractor (default, OdometryPipeline.cpp:68), 1 = ShiTomasiFeatureExtractor
     double shitomasi_quality = 0.4;                      // ShiTomasiFeatureExtractor.h:10
+    int pipe_depth = 605;     // jobs the front-end may be ahead of the back-end: dlib::pipe<Job> job_pipe(605), OdometryPipeline.cpp:26
 };
 
 class OdometryPipeline;
