@@ -543,7 +543,7 @@ def main():
         "pipeline_stats": {k_: st[k_] for k_ in ("lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls",
                                                  "ba_obs", "ba_points", "heuristic_motion", "n_landmarks")},
         "host_stage_seconds_per_step": {k_: round(st[k_], 4) for k_ in ("t_lk", "t_detect", "t_pnp", "t_tri", "t_ba", "t_pnp_kernel", "t_ba_kernel",
-                                                                           "t_tri_essential", "t_tri_pose", "tri_hypotheses")},
+                                                                           "t_tri_essential", "t_tri_pose", "tri_hypotheses", "tri_ahead")},
         "trajectory_error_m": {"mean": round(float(terr.mean()), 3), "max": round(float(terr.max()), 3),
                                "travelled": round(float(np.linalg.norm(g[-1])), 1)},
         "input_generation_s": round(t_gen, 2),

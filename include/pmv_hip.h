@@ -243,14 +243,15 @@ void pmv_pipeline_get_poses(const pmv_pipeline_result* r, double* out12); /* per
 int pmv_pipeline_num_frames(const pmv_pipeline_result* r);
 int pmv_pipeline_frame_feature_count(const pmv_pipeline_result* r, int k);
 void pmv_pipeline_get_frame_features(const pmv_pipeline_result* r, int k, int* out3); /* (column,row,landmark id|-1) */
-/* Run statistics: pmv_pipeline_stats_count() (= 24) doubles, in this order:
+/* Run statistics: pmv_pipeline_stats_count() (= 25) doubles, in this order:
  *   [0] lk_calls [1] lk_points [2] detect_calls [3] pnp_calls [4] pnp_points [5] tri_calls [6] ba_calls [7] ba_obs [8] ba_points
  *   [9] heuristic_motion (frames whose pose came from motionHeuristics' fallback branch) [10] run seconds [11] init_offset
  *   [12] live landmarks at the end [13] scale; wall seconds per stage as seen by the calling host threads: [14] t_lk [15] t_detect
  *   [16] t_pnp [17] t_tri [18] t_ba [19] t_pnp_kernel [20] t_ba_kernel [21] t_tri_essential [22] t_tri_pose; [23] five-point
- *   RANSAC samples drawn. The caller's buffer must hold pmv_pipeline_stats_count() doubles. */
+ *   RANSAC samples drawn [24] tri_ahead: two-view calls whose findEssentialMat + recoverPose had been computed ahead of the back-end
+ *   by a helper thread (two-thread pipeline). The caller's buffer must hold pmv_pipeline_stats_count() doubles. */
 int pmv_pipeline_stats_count(void);
-void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out24);
+void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out25);
 
 #ifdef __cplusplus
 }

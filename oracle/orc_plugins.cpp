@@ -132,7 +132,7 @@ int orc_pipeline_num_frames(void* h) { return vo::pipeline_num_frames(*(vo::Pipe
 int orc_pipeline_frame_feature_count(void* h, int k) { return vo::pipeline_frame_feature_count(*(vo::PipelineRun*)h, k); }
 void orc_pipeline_get_frame_features(void* h, int k, int* out) { vo::pipeline_get_frame_features(*(vo::PipelineRun*)h, k, out); }
 int orc_pipeline_stats_count(void) { return vo::PIPELINE_STATS_COUNT; }
-void orc_pipeline_get_stats(void* h, double* out24) { vo::pipeline_get_stats(*(vo::PipelineRun*)h, out24); }
+void orc_pipeline_get_stats(void* h, double* out25) { vo::pipeline_get_stats(*(vo::PipelineRun*)h, out25); }
 }
 
 // ---- host-logic probes for the CPU test-suite (KA5/KA6/KA9/KA10 of SURVEY.md §8c) ------------------------------------------

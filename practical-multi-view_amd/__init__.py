@@ -56,7 +56,7 @@ class PipelineParams(C.Structure):
 
 STAT_KEYS = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
              "ba_points", "heuristic_motion", "seconds", "init_offset", "n_landmarks", "scale", "t_lk", "t_detect", "t_pnp", "t_tri",
-             "t_ba", "t_pnp_kernel", "t_ba_kernel", "t_tri_essential", "t_tri_pose", "tri_hypotheses"]
+             "t_ba", "t_pnp_kernel", "t_ba_kernel", "t_tri_essential", "t_tri_pose", "tri_hypotheses", "tri_ahead"]
 
 
 class PipelineResult:

@@ -375,5 +375,5 @@ int pmv_pipeline_num_frames(const pmv_pipeline_result* r) { return vo::pipeline_
 int pmv_pipeline_frame_feature_count(const pmv_pipeline_result* r, int k) { return vo::pipeline_frame_feature_count(r->run, k); }
 void pmv_pipeline_get_frame_features(const pmv_pipeline_result* r, int k, int* out) { vo::pipeline_get_frame_features(r->run, k, out); }
 int pmv_pipeline_stats_count(void) { return vo::PIPELINE_STATS_COUNT; }
-void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out24) { vo::pipeline_get_stats(r->run, out24); }
+void pmv_pipeline_get_stats(const pmv_pipeline_result* r, double* out25) { vo::pipeline_get_stats(r->run, out25); }
 }

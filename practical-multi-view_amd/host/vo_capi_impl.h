@@ -92,14 +92,14 @@ inline void pipeline_get_frame_features(const PipelineRun& run, int k, int* out)
 }
 // PIPELINE_STATS_COUNT doubles: counters, run seconds, and per-stage wall seconds of the calling host threads (the field list is
 // documented at pmv_pipeline_get_stats in include/pmv_hip.h)
-constexpr int PIPELINE_STATS_COUNT = 24;
-inline void pipeline_get_stats(const PipelineRun& run, double* out24) {
+constexpr int PIPELINE_STATS_COUNT = 25;
+inline void pipeline_get_stats(const PipelineRun& run, double* out25) {
     const Stats& s = run.pipe.stats;
     const double v[PIPELINE_STATS_COUNT] = {(double)s.lk_calls, (double)s.lk_points, (double)s.detect_calls, (double)s.pnp_calls, (double)s.pnp_points,
                           (double)s.tri_calls, (double)s.ba_calls, (double)s.ba_obs, (double)s.ba_points, (double)s.heuristic_motion,
                           run.seconds, (double)run.pipe.init_offset, (double)run.pipe.feats3d.size(), run.pipe.scale,
-                          s.t_lk, s.t_detect, s.t_pnp, s.t_tri, s.t_ba, s.t_pnp_kernel, s.t_ba_kernel, s.t_tri_essential, s.t_tri_pose, s.tri_hypotheses};
-    memcpy(out24, v, sizeof(v));
+                          s.t_lk, s.t_detect, s.t_pnp, s.t_tri, s.t_ba, s.t_pnp_kernel, s.t_ba_kernel, s.t_tri_essential, s.t_tri_pose, s.tri_hypotheses, (double)s.tri_ahead};
+    memcpy(out25, v, sizeof(v));
 }
 
 }  // namespace vo

@@ -674,6 +674,7 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
             have_pose = true;
         }
         prefetch_hits++;
+        tracker->stats.tri_ahead++;
     } else {
         ok = find_essential_mat(p1.data(), p2.data(), n, tracker->camera, 0.99, 1.0, E, mask, &drawn, inline_e ? pool.get() : nullptr, inline_e ? workers : 1,
                                 use_hypothesis_hook ? this : nullptr);

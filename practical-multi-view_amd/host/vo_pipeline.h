@@ -196,6 +196,7 @@ struct Stats {
     // wall time per stage as seen by the calling host thread (adapter gather/scatter + plugin kernel + sync)
     double t_lk = 0, t_detect = 0, t_pnp = 0, t_tri = 0, t_ba = 0, t_pnp_kernel = 0, t_ba_kernel = 0;
     double t_tri_essential = 0, t_tri_pose = 0, tri_hypotheses = 0;
+    long tri_ahead = 0;   // triangulate() calls whose two-view geometry had been computed ahead by a prefetch helper
     HostProf hp;   // inside t_tri: five-point RANSAC, recoverPose; RANSAC samples drawn
 };
 
