@@ -84,7 +84,7 @@ def test_threaded_schedule_gives_identical_results(pmv, gpu_ctx_factory):
     ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096)
     ctx.frames_stage(0, frames)
     a = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=0)
-    b = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1)
+    b = ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1, n_threads=4)
     # the two-thread schedule computes the two-view geometry ahead of the back-end (helper threads + the auxiliary device lane)
     # (a pair the back-end reaches before a helper has started it is computed inline: <=, not ==)
     assert 1 <= b.stats["tri_ahead"] <= b.stats["tri_calls"] and a.stats["tri_ahead"] == 0
