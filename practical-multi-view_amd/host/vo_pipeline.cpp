@@ -176,6 +176,29 @@ static void index_feat_corr(Frame& fr) {
         if (std::shared_ptr<Feature> k = p.first.lock()) { k->corr_slot = &p.second; k->corr_owner = &fr.feat_corr; k->corr_feat = p.second.lock().get(); }
 }
 
+// front-end: the gather list of solvePnP(src, next) (see PnPLink). `next` must be at its final address with all its features in.
+static void build_pnp_links(Frame& src, Frame& next) {
+    for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }
+    src.pnp_links.clear();
+    src.pnp_links.reserve(src.map.size());
+    for (auto& p : src.map) {
+        PnPLink L;
+        L.src_val = &p.second; L.key = &p.first;
+        if (p.first->corr_owner == (const void*)&src.feat_corr) {   // this very object is the key of its feat_corr entry
+            Feature* f = p.first->corr_feat;
+            if (!f) L.kind = 0;
+            else if (f->map_owner == (const void*)&next.map) { L.kind = 1; L.next_slot = f->map_slot; L.f = f; }
+            else {   // not a key object of next.map: an equal key's node is where next.map[f] lands; no such node -> operator[] would insert
+                std::shared_ptr<Feature> fs = p.first->corr_slot->lock();
+                auto it = fs ? next.map.find(fs) : next.map.end();
+                if (it != next.map.end()) { L.kind = 1; L.next_slot = &it->second; L.f = f; }
+            }
+        }
+        src.pnp_links.push_back(L);
+    }
+    src.pnp_links_for = &next.map;
+}
+
 void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
     const int j = src.frame;
     std::vector<float> obj_points, img_points;
@@ -184,26 +207,7 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
     std::vector<std::weak_ptr<Feature3D>> local_feats3d;
     HostProfScope* hps = new HostProfScope(tracker->stats.hp.t[0]);
     obj_points.reserve(3 * src.map.size()); img_points.reserve(2 * src.map.size()); local_feats3d.reserve(src.map.size());
-    for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }   // next.map[f] below without hashing
-    for (auto& p : src.map) {
-        std::shared_ptr<Feature3D> f3d = p.second.lock();    // (expired() + lock() in the reference: one atomic round trip here)
-        if (!f3d) continue;
-        // src.feat_corr[p.first]: the entry found by coordinate equality. If this very object is the entry's key the front-end
-        // left its address in corr_slot; otherwise (same-pixel twin, or no correspondence) look it up as the reference does —
-        // operator[] then inserts the empty entry of quirk Q10.
-        Feature* f;
-        if (p.first->corr_owner == (const void*)&src.feat_corr) {
-            f = p.first->corr_feat;                       // no reference-count traffic on the (front-end-created) feature
-            if (!f) continue;
-            if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
-            else next.map[p.first->corr_slot->lock()] = std::weak_ptr<Feature3D>(f3d);
-        } else {
-            std::shared_ptr<Feature> fs = src.feat_corr[p.first].lock();
-            if (!fs) continue;
-            f = fs.get();
-            if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
-            else next.map[fs] = std::weak_ptr<Feature3D>(f3d);
-        }
+    const auto take = [&](std::shared_ptr<Feature3D>& f3d, const Feature* f) {   // :22-27 for one landmark / image point pair
         f3d->transformInv(tracker->R[j], tracker->t[j]);
         float px = f3d->x, py = f3d->y, pz = f3d->z;
         pz *= -1;
@@ -211,6 +215,41 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
         img_points.push_back((float)f->column); img_points.push_back((float)f->row);
         f3d->transform(tracker->R[j], tracker->t[j]);       // float round trip (quirk Q7)
         local_feats3d.push_back(std::move(f3d));
+    };
+    // one src.map entry the way the reference walks it. src.feat_corr[p.first]: the entry found by coordinate equality. If this very
+    // object is the entry's key the front-end left its address in corr_slot; otherwise (same-pixel twin, or no correspondence) look it
+    // up as the reference does - operator[] then inserts the empty entry of quirk Q10.
+    const auto slow_entry = [&](const std::shared_ptr<Feature>& key, std::shared_ptr<Feature3D>& f3d) {
+        Feature* f;
+        if (key->corr_owner == (const void*)&src.feat_corr) {
+            f = key->corr_feat;                       // no reference-count traffic on the (front-end-created) feature
+            if (!f) return;
+            if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
+            else next.map[key->corr_slot->lock()] = std::weak_ptr<Feature3D>(f3d);
+        } else {
+            std::shared_ptr<Feature> fs = src.feat_corr[key].lock();
+            if (!fs) return;
+            f = fs.get();
+            if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
+            else next.map[fs] = std::weak_ptr<Feature3D>(f3d);
+        }
+        take(f3d, f);
+    };
+    if (src.pnp_links_for == (const void*)&next.map && src.pnp_links.size() == src.map.size()) {
+        // the front-end's list: same entries in the same order, only the landmark's liveness is looked up here
+        for (const PnPLink& L : src.pnp_links) {
+            std::shared_ptr<Feature3D> f3d = L.src_val->lock();    // (expired() + lock() in the reference: one atomic round trip here)
+            if (!f3d) continue;
+            if (L.kind == 1) { *L.next_slot = std::weak_ptr<Feature3D>(f3d); take(f3d, L.f); }
+            else if (L.kind == 2) slow_entry(*L.key, f3d);
+        }
+    } else {
+        for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }   // next.map[f] below without hashing
+        for (auto& p : src.map) {
+            std::shared_ptr<Feature3D> f3d = p.second.lock();
+            if (!f3d) continue;
+            slow_entry(p.first, f3d);
+        }
     }
     delete hps;
     std::vector<int> inliers;
@@ -411,6 +450,7 @@ void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
             }
     }
     frames.push_back(std::make_shared<Frame>(std::move(frame)));   // (the reference copies; callers only read frame.frame afterwards)
+    build_pnp_links(*frames[frames.size() - 2], *frames.back());
 }
 
 void OdometryPipeline::motionHeuristics(Mat3& _R, Vec3& _t, int j) {   // :171-208
@@ -560,6 +600,7 @@ void OdometryPipeline::run_threaded() {
         }
         const int frame_no = frame.frame;
         std::shared_ptr<Frame> stored = std::make_shared<Frame>(std::move(frame));   // built outside the lock
+        build_pnp_links(*prev, *stored);   // the back-end reaches (prev, stored) after the next frame is in: nobody else touches either now
         {
             std::unique_lock<std::mutex> lk(mu);
             frames.push_back(std::move(stored));

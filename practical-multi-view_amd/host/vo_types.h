@@ -136,12 +136,26 @@ struct ImageView {
 };
 
 // Frame.h:12-105
+// One entry of Frame::map as OpenCVEPnPSolver's gather loop (OpenCVEPnPSolver.cpp:13-28) will meet it, as far as that is known once
+// the next frame exists (everything but whether the landmark is still alive): built by the front-end thread, which has the
+// features of both frames in cache, so that the back-end's loop is one pass over a flat list instead of a walk through the
+// hash-map nodes and feature objects of two frames (host-side shortcut like Feature::map_slot: no effect on any result).
+struct PnPLink {
+    std::weak_ptr<Feature3D>* src_val = nullptr;          // &entry.second: the landmark of the source feature
+    std::weak_ptr<Feature3D>* next_slot = nullptr;        // kind 1: &next.map[corresponding feature] (the node operator[] would reach)
+    const Feature* f = nullptr;                           // kind 1: the corresponding feature (its coordinates are the image point)
+    const std::shared_ptr<Feature>* key = nullptr;        // &entry.first (kind 2 runs the reference's lookups on it)
+    unsigned char kind = 2;                               // 0 no correspondence; 1 as above; 2 same-pixel twin / absent node: the slow path, in sequence
+};
+
 class Frame {
 public:
     std::unordered_map<std::shared_ptr<Feature>, std::weak_ptr<Feature3D>, Feature::Hasher> map;
     std::unordered_map<std::weak_ptr<Feature>, std::weak_ptr<Feature>, Feature::Hasher, Feature::WeakEq> feat_corr;
     ImageView bw;
     int frame = 0;
+    std::vector<PnPLink> pnp_links;       // one per map entry, in iteration order; valid for solvePnP(*this, next) iff ...
+    const void* pnp_links_for = nullptr;  // ... == &next.map (a moved or copied frame has another address: self-invalidating)
 
     Frame() {}
     explicit Frame(const ImageView& img) : bw(img) {}
