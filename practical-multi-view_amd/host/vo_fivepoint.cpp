@@ -642,19 +642,29 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
         pool->begin();
     }
     HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[4]);
-    for (auto& p : src.map) { p.first->map_slot = &p.second; p.first->map_owner = &src.map; }     // src.map[..] / next.map[..] below without hashing
-    for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }
-    for (auto& p : src.feat_corr) {
-        if (p.first.expired() || p.second.expired()) continue;
-        std::shared_ptr<Feature> fst = p.first.lock();
-        std::shared_ptr<Feature> sec = p.second.lock();
-        p1.push_back(fst->column); p1.push_back(fst->row);     // integer cv::Point (quirk Q12)
-        p2.push_back(sec->column); p2.push_back(sec->row);
-        p1_ptr.push_back(fst);
-        p2_ptr.push_back(sec);
+    // the front-end's list of this pair (TriLink): the same correspondences in the same order, with the map nodes that receive the landmarks
+    const bool flat = src.tri_links_src == (const void*)&src.map && src.pnp_links_for == (const void*)&next.map;
+    if (flat) {
+        p1.reserve(2 * src.tri_links.size()); p2.reserve(2 * src.tri_links.size());
+        for (const TriLink& T : src.tri_links) {
+            p1.push_back(T.fst->column); p1.push_back(T.fst->row);     // integer cv::Point (quirk Q12)
+            p2.push_back(T.sec->column); p2.push_back(T.sec->row);
+        }
+    } else {
+        for (auto& p : src.map) { p.first->map_slot = &p.second; p.first->map_owner = &src.map; }     // src.map[..] / next.map[..] below without hashing
+        for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }
+        for (auto& p : src.feat_corr) {
+            if (p.first.expired() || p.second.expired()) continue;
+            std::shared_ptr<Feature> fst = p.first.lock();
+            std::shared_ptr<Feature> sec = p.second.lock();
+            p1.push_back(fst->column); p1.push_back(fst->row);     // integer cv::Point (quirk Q12)
+            p2.push_back(sec->column); p2.push_back(sec->row);
+            p1_ptr.push_back(fst);
+            p2_ptr.push_back(sec);
+        }
     }
     delete hpg;
-    const int n = (int)p1_ptr.size();
+    const int n = (int)(p1.size() / 2);
     std::vector<uint8_t> mask;
     std::vector<double> tri;
     double E[9];
@@ -709,8 +719,13 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
             f3d->transform(tracker->R[j], tracker->t[j]);
             tracker->feats3d.push_back(f3d);
             f3d->self = std::prev(tracker->feats3d.end());
-            if (p2_ptr[i]->map_owner == (const void*)&next.map) *p2_ptr[i]->map_slot = std::weak_ptr<Feature3D>(f3d); else next.map[p2_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
-            if (p1_ptr[i]->map_owner == (const void*)&src.map) *p1_ptr[i]->map_slot = std::weak_ptr<Feature3D>(f3d); else src.map[p1_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
+            if (flat) {
+                *src.tri_links[i].next_slot = std::weak_ptr<Feature3D>(f3d);
+                *src.tri_links[i].src_slot = std::weak_ptr<Feature3D>(f3d);
+            } else {
+                if (p2_ptr[i]->map_owner == (const void*)&next.map) *p2_ptr[i]->map_slot = std::weak_ptr<Feature3D>(f3d); else next.map[p2_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
+                if (p1_ptr[i]->map_owner == (const void*)&src.map) *p1_ptr[i]->map_slot = std::weak_ptr<Feature3D>(f3d); else src.map[p1_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
+            }
         }
     }
 }

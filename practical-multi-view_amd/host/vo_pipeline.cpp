@@ -184,6 +184,7 @@ static void build_pnp_links(Frame& src, Frame& next) {
     for (auto& p : src.map) {
         PnPLink L;
         L.src_val = &p.second; L.key = &p.first;
+        L.key_column = p.first->column; L.key_row = p.first->row;
         if (p.first->corr_owner == (const void*)&src.feat_corr) {   // this very object is the key of its feat_corr entry
             Feature* f = p.first->corr_feat;
             if (!f) L.kind = 0;
@@ -197,6 +198,24 @@ static void build_pnp_links(Frame& src, Frame& next) {
         src.pnp_links.push_back(L);
     }
     src.pnp_links_for = &next.map;
+    // the two-view gather (OpenCVFivePointTri.cpp:9-22) and where its landmarks go (:47-50)
+    for (auto& p : src.map) { p.first->map_slot = &p.second; p.first->map_owner = &src.map; }   // (src's hints pointed into the map of its own build step)
+    src.tri_links.clear();
+    src.tri_links.reserve(src.feat_corr.size());
+    bool complete = true;
+    for (auto& p : src.feat_corr) {
+        if (p.first.expired() || p.second.expired()) continue;
+        std::shared_ptr<Feature> fst = p.first.lock(), sec = p.second.lock();
+        TriLink T;
+        T.fst = fst.get(); T.sec = sec.get();
+        if (fst->map_owner == (const void*)&src.map) T.src_slot = fst->map_slot;
+        else { auto it = src.map.find(fst); if (it != src.map.end()) T.src_slot = &it->second; }
+        if (sec->map_owner == (const void*)&next.map) T.next_slot = sec->map_slot;
+        else { auto it = next.map.find(sec); if (it != next.map.end()) T.next_slot = &it->second; }
+        if (!T.src_slot || !T.next_slot) complete = false;   // operator[] would insert a node: leave this pair to the reference's loop
+        src.tri_links.push_back(T);
+    }
+    src.tri_links_src = complete ? (const void*)&src.map : nullptr;
 }
 
 void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
@@ -301,11 +320,15 @@ void BundleAdjustmentBase::apply(Frame& f) {
         cam_frame.push_back(i);
         tr_opt.push_back(rod[0]); tr_opt.push_back(rod[1]); tr_opt.push_back(rod[2]);
         tr_opt.push_back(-tracker->t[i].v[0]); tr_opt.push_back(-tracker->t[i].v[1]); tr_opt.push_back(-tracker->t[i].v[2]);
-        for (auto& p : frame->map) {
-            std::shared_ptr<Feature3D> f3d = p.second.lock();
+        const bool flat = frame->links_cover_map();   // the front-end's list holds the same entries in the same order
+        const size_t n_entries = flat ? frame->pnp_links.size() : 0;
+        auto entry = frame->map.begin();
+        for (size_t e = 0; flat ? e < n_entries : entry != frame->map.end(); flat ? (void)++e : (void)++entry) {
+            std::shared_ptr<Feature3D> f3d = flat ? frame->pnp_links[e].src_val->lock() : entry->second.lock();
             if (!f3d) continue;
-            const Feature* ft = p.first.get();
-            obs.push_back((double)ft->column); obs.push_back((double)ft->row);
+            const int ft_column = flat ? frame->pnp_links[e].key_column : entry->first->column;
+            const int ft_row = flat ? frame->pnp_links[e].key_row : entry->first->row;
+            obs.push_back((double)ft_column); obs.push_back((double)ft_row);
             // index of the landmark in first-seen order (p3d_opt of the reference); landmark ids are dense creation numbers
             const size_t lid = (size_t)f3d->id;
             if (lid >= seen_epoch.size()) { seen_epoch.resize(lid + 4096, 0); seen_index.resize(lid + 4096, 0); }

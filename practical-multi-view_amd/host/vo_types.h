@@ -145,7 +145,14 @@ struct PnPLink {
     std::weak_ptr<Feature3D>* next_slot = nullptr;        // kind 1: &next.map[corresponding feature] (the node operator[] would reach)
     const Feature* f = nullptr;                           // kind 1: the corresponding feature (its coordinates are the image point)
     const std::shared_ptr<Feature>* key = nullptr;        // &entry.first (kind 2 runs the reference's lookups on it)
+    int key_column = 0, key_row = 0;                      // the entry's own feature (the observation CeresBundleAdjustment.cpp:28-33 reads)
     unsigned char kind = 2;                               // 0 no correspondence; 1 as above; 2 same-pixel twin / absent node: the slow path, in sequence
+};
+// One entry of Frame::feat_corr as OpenCVFivePointTri's gather loop (OpenCVFivePointTri.cpp:9-22) will meet it: both features and the
+// nodes of the two frames' maps that receive the triangulated landmark (:47-50). Built by the front-end like PnPLink.
+struct TriLink {
+    Feature* fst = nullptr; Feature* sec = nullptr;
+    std::weak_ptr<Feature3D>* src_slot = nullptr; std::weak_ptr<Feature3D>* next_slot = nullptr;
 };
 
 class Frame {
@@ -156,6 +163,9 @@ public:
     int frame = 0;
     std::vector<PnPLink> pnp_links;       // one per map entry, in iteration order; valid for solvePnP(*this, next) iff ...
     const void* pnp_links_for = nullptr;  // ... == &next.map (a moved or copied frame has another address: self-invalidating)
+    std::vector<TriLink> tri_links;       // one per live feat_corr entry, in iteration order; valid under the same condition + ...
+    const void* tri_links_src = nullptr;  // ... == &map (of this frame)
+    bool links_cover_map() const { return pnp_links_for != nullptr && pnp_links.size() == map.size() && tri_links_src == (const void*)&map; }
 
     Frame() {}
     explicit Frame(const ImageView& img) : bw(img) {}
@@ -168,7 +178,8 @@ public:
     }
     int count3DPoints() const {   // Frame.cpp:14-24
         int c = 0;
-        for (auto& p : map) if (!p.second.expired()) c++;
+        if (links_cover_map()) { for (const PnPLink& L : pnp_links) if (!L.src_val->expired()) c++; }   // the same entries, from the flat list
+        else for (auto& p : map) if (!p.second.expired()) c++;
         return c;
     }
     bool hasNeighbor(const Feature& f, int dist = 5) const {   // Frame.cpp:3-12
