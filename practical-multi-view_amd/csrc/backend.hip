@@ -193,13 +193,16 @@ void pmv::pnp_finish(pmv_ctx* ctx, BackendBuffers* b, const float* obj_xyz, cons
 
 extern "C" {
 
+static bool stamps_on() { static const bool on = getenv("PMV_BA_STAMPS") != nullptr; return on; }
+
 int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec,
                    int iterations, float reproj_err, double confidence, int* out_inliers, int* out_n_inliers) {
     int rc = pnp_check(ctx, obj_xyz, img_xy, m, K, rvec, tvec, iterations, confidence, out_inliers, out_n_inliers);
     if (rc) return rc;
     tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
-    if (const char* dump = getenv("PMV_DUMP_PNP")) {   // debug: append the inputs of every call to a file
+    static const char* const dump = getenv("PMV_DUMP_PNP");   // (the diagnostic switches are read once per process: getenv walks the whole environment)
+    if (dump) {   // debug: append the inputs of every call to a file
         if (FILE* f = fopen(dump, "ab")) {
             fwrite(&m, 4, 1, f); fwrite(obj_xyz, 12, m, f); fwrite(img_xy, 8, m, f); fwrite(K, 8, 9, f); fwrite(rvec, 8, 3, f); fwrite(tvec, 8, 3, f);
             fclose(f);
@@ -212,7 +215,7 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     pnp_prepare(b, obj_xyz, img_xy, m, K, iterations, reproj_err, confidence, &P, &in_bytes);
     CKC(hipMemcpyAsync(b->d_pnp_in, b->h_stage, in_bytes, hipMemcpyHostToDevice, s));
     CKC(launch_pnp(s, P.obj, P.img, m, P.K, P.samples, iterations, P.thr, confidence, P.models, P.masks, P.counts,
-                   P.rt_out, P.inliers, P.info, P.host_out, getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr));
+                   P.rt_out, P.inliers, P.info, P.host_out, stamps_on() ? b->d_stamps : nullptr));
     CKC(hipStreamSynchronize(s));   // the refit kernel wrote [rt | info | inliers] straight into the pinned block
     pnp_finish(ctx, b, obj_xyz, img_xy, m, K, rvec, tvec, iterations, reproj_err, confidence, in_bytes, out_inliers, out_n_inliers);
     return PMV_OK;
@@ -350,7 +353,7 @@ int pmv::ba_prepare(pmv_ctx* ctx, BackendBuffers* b, const double* cams, int nc,
     A.nc = nc; A.np = np; A.nobs = n_obs; A.max_iterations = max_iterations; A.huber = huber_delta;
     A.x = b->d_x; A.cand = b->d_cand; A.scale = b->d_scale; A.diag = b->d_diag; A.D2 = b->d_D2; A.step = b->d_step; A.res = b->d_res; A.J = b->d_J;
     A.Einv = b->d_Einv; A.gp = b->d_gp; A.Yd = b->d_Yd; A.Wd = b->d_Wd; A.S = b->d_S; A.rhs = b->d_rhs; A.Gpart = b->d_Gpart; A.summary = d_sum;
-    A.stamps = getenv("PMV_BA_STAMPS") ? b->d_stamps : nullptr;
+    A.stamps = stamps_on() ? b->d_stamps : nullptr;
     A.out = nullptr;
     A.tiles_r = tiles_r; A.tiles_c = tiles_c;
     A.ldw = A.tiles_c * 16;
@@ -374,7 +377,8 @@ int pmv::ba_prepare(pmv_ctx* ctx, BackendBuffers* b, const double* cams, int nc,
 void pmv::ba_finish(pmv_ctx* ctx, BackendBuffers* b, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
                     const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations, pmv_ba_summary* summary) {
     const double* h_out = (const double*)b->h_stage;
-    if (getenv("PMV_BA_TRACE")) {   // diagnostic: first / last camera before and after the solve
+    static const bool ba_trace = getenv("PMV_BA_TRACE") != nullptr;
+    if (ba_trace) {   // diagnostic: first / last camera before and after the solve
         fprintf(stderr, "[ba-trace] nc=%d np=%d nobs=%d cost %.15g -> %.15g it %d ok %d\n", nc, np, n_obs, h_out[0], h_out[1], (int)h_out[2], (int)h_out[3]);
         for (int c : {0, nc - 1}) {
             fprintf(stderr, "[ba-trace]   cam %d in ", c);

@@ -287,7 +287,8 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     CKC(hipMemcpyAsync(ctx->d_prev_xy, ctx->h_prev_xy, (size_t)n * 8 + (size_t)nb * 4, hipMemcpyHostToDevice, ctx->s_front));
     LKParams P;
     P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f;
-    if (!ctx->d_lk_stamps && getenv("PMV_LK_STAMPS")) { CKC(hipMalloc(&ctx->d_lk_stamps, 16 * 8)); CKC(hipMemset(ctx->d_lk_stamps, 0, 16 * 8)); }
+    static const bool lk_stamps = getenv("PMV_LK_STAMPS") != nullptr;   // read once per process
+    if (!ctx->d_lk_stamps && lk_stamps) { CKC(hipMalloc(&ctx->d_lk_stamps, 16 * 8)); CKC(hipMemset(ctx->d_lk_stamps, 0, 16 * 8)); }
     P.stamps = ctx->d_lk_stamps;
     P.counters = ctx->d_lk_counters;
     CKC(launch_lk(ctx->s_front, ctx->d_slots + (size_t)prev_slot * L.slot_bytes, ctx->d_slots + (size_t)next_slot * L.slot_bytes,
