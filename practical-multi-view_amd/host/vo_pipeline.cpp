@@ -297,13 +297,15 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
 void BundleAdjustmentBase::apply(Frame& f) {
     const int fn = (int)f.frame + 1;
     const int n = std::min(tracker->cfg.bundle_size, fn);
-    std::vector<int> cam_frame;                 // window frames in order (skipping 0)
-    std::vector<double> tr_opt;                 // 6 per window frame
-    std::vector<double> obs;                    // 2 per residual block
-    std::vector<int> obs_cam, obs_pt;
+    // (the work vectors are members: a solve every other frame would otherwise grow each of them from empty again)
+    std::vector<int>& cam_frame = w_cam_frame;        // window frames in order (skipping 0)
+    std::vector<double>& tr_opt = w_tr_opt;           // 6 per window frame
+    std::vector<double>& obs = w_obs;                 // 2 per residual block
+    std::vector<int>& obs_cam = w_obs_cam; std::vector<int>& obs_pt = w_obs_pt;
     const unsigned epoch = ++epoch_counter;   // p3d_index of the reference, as epoch-stamped arrays over the landmark ids
-    std::vector<std::shared_ptr<Feature3D>> p3d_ptr;
-    std::vector<double> p3d_opt;
+    std::vector<Feature3D*>& p3d_ptr = w_p3d_ptr;     // (raw: nothing erases a landmark between the gather and the update below; one thread)
+    std::vector<double>& p3d_opt = w_p3d_opt;
+    cam_frame.clear(); tr_opt.clear(); obs.clear(); obs_cam.clear(); obs_pt.clear(); p3d_ptr.clear(); p3d_opt.clear();
     HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[2]);
     std::vector<std::shared_ptr<Frame>> window((size_t)n);   // snapshot under the lock: the front-end thread may be appending
     {
@@ -338,15 +340,17 @@ void BundleAdjustmentBase::apply(Frame& f) {
                 pi = (int)p3d_ptr.size();
                 seen_index[lid] = pi;
                 p3d_opt.push_back(f3d->x); p3d_opt.push_back(f3d->y); p3d_opt.push_back(f3d->z);
-                p3d_ptr.push_back(std::move(f3d));
+                p3d_ptr.push_back(f3d.get());
             } else pi = seen_index[lid];
             obs_cam.push_back(ci); obs_pt.push_back(pi);
         }
     }
     const int n_obs = (int)obs_cam.size();
     // Only parameter blocks that appear in a residual block are part of the Ceres problem: compact the cameras.
-    std::vector<int> remap(cam_frame.size(), -1);
-    std::vector<double> cams_c;
+    std::vector<int>& remap = w_remap;
+    remap.assign(cam_frame.size(), -1);
+    std::vector<double>& cams_c = w_cams_c;
+    cams_c.clear();
     int nc = 0;
     {
         std::vector<uint8_t> used(cam_frame.size(), 0);
