@@ -12,6 +12,7 @@ namespace pmv {
 constexpr int MAX_HYP = 1024;
 
 struct BackendBuffers {
+    unsigned done_seq = 0;   // sequence number of the last call that signals its completion through the result block
     // BA problem
     double *d_cams = nullptr, *d_pts = nullptr, *d_obs = nullptr, *d_K = nullptr;
     int *d_cam_idx = nullptr, *d_pt_idx = nullptr, *d_pobs_start = nullptr, *d_pobs_list = nullptr, *d_cobs_start = nullptr, *d_cobs_list = nullptr;
@@ -68,7 +69,7 @@ hipError_t launch_ba_multi(hipStream_t s, const BAArgs& A, void* d_state, double
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
                       double* d_rt_out, int* d_inliers, int* d_info, char* host_out /* mapped pinned [rt 48 B | info 16 B | inliers] */,
-                      unsigned long long* d_stamps /* diagnostic, may be null */);
+                      unsigned long long* d_stamps /* diagnostic, may be null */, unsigned done_seq = 0 /* see pnp_select_refit_body */);
 
 // one problem of a batched multi-kernel LM launch chain: the arguments launch_ba_multi derives for a single solve, kept in device memory
 struct BAProb {

@@ -214,9 +214,25 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     size_t in_bytes = 0;
     pnp_prepare(b, obj_xyz, img_xy, m, K, iterations, reproj_err, confidence, &P, &in_bytes);
     CKC(hipMemcpyAsync(b->d_pnp_in, b->h_stage, in_bytes, hipMemcpyHostToDevice, s));
+    // the refit kernel writes [rt | info | inliers] straight into the pinned block and, last, this call's sequence number into the
+    // block's fourth info word: the result is read as soon as that store lands (PMV_BACK_WAIT=sync: hipStreamSynchronize instead)
+    static const bool flag_wait = !(getenv("PMV_BACK_WAIT") && !strcmp(getenv("PMV_BACK_WAIT"), "sync"));
+    volatile unsigned* done_word = (volatile unsigned*)((char*)b->h_stage + ((in_bytes + 63) & ~(size_t)63) + 60);
+    if (++b->done_seq == 0) b->done_seq = 1;
+    *done_word = 0;
     CKC(launch_pnp(s, P.obj, P.img, m, P.K, P.samples, iterations, P.thr, confidence, P.models, P.masks, P.counts,
-                   P.rt_out, P.inliers, P.info, P.host_out, stamps_on() ? b->d_stamps : nullptr));
-    CKC(hipStreamSynchronize(s));   // the refit kernel wrote [rt | info | inliers] straight into the pinned block
+                   P.rt_out, P.inliers, P.info, P.host_out, stamps_on() ? b->d_stamps : nullptr, flag_wait ? b->done_seq : 0u));
+    if (flag_wait) {
+        (void)hipStreamQuery(s);   // lets the runtime retire the commands of earlier calls now, while the GPU works on this one
+        for (unsigned spins = 1;; spins++) {
+            if (__atomic_load_n(done_word, __ATOMIC_ACQUIRE) == b->done_seq) break;
+            if ((spins & 0xffffu) == 0) {   // a faulted launch never signals: ask the runtime now and then
+                const hipError_t e = hipStreamQuery(s);
+                if (e != hipSuccess && e != hipErrorNotReady) CKC(e);
+            }
+            __builtin_ia32_pause();
+        }
+    } else CKC(hipStreamSynchronize(s));
     pnp_finish(ctx, b, obj_xyz, img_xy, m, K, rvec, tvec, iterations, reproj_err, confidence, in_bytes, out_inliers, out_n_inliers);
     return PMV_OK;
 }

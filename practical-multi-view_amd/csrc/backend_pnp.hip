@@ -514,7 +514,9 @@ __device__ __forceinline__ void pnp_select_refit_body(const float* __restrict__ 
                                                       const uint8_t* __restrict__ masks, const int* __restrict__ counts,
                                                       int n_hyp, double confidence, double* __restrict__ rt_out,
                                                       int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out,
-                                                      unsigned long long* stamps) {
+                                                      unsigned long long* stamps, const unsigned done_seq) {
+    // done_seq != 0: after the result block in mapped pinned memory is complete, its last info word takes this call's sequence number -
+    // the host spins on that word instead of asking the runtime to synchronise the stream (a marker packet and its signal later)
     __shared__ RefitShared sh;
     const unsigned long long t_start = __builtin_readcyclecounter();
     unsigned long long t_lm0 = 0;
@@ -544,6 +546,7 @@ __device__ __forceinline__ void pnp_select_refit_body(const float* __restrict__ 
             if (host_out) {
                 for (int i = 0; i < 6; i++) ((double*)host_out)[i] = models[l * 6 + i];
                 ((int*)(host_out + 48))[0] = 0; ((int*)(host_out + 48))[1] = sh.last + 1;
+                if (done_seq) { __threadfence_system(); __hip_atomic_store((unsigned*)(host_out + 60), done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
             }
         }
         return;
@@ -725,6 +728,11 @@ __device__ __forceinline__ void pnp_select_refit_body(const float* __restrict__ 
         if (tid == 0) { ((int*)(host_out + 48))[0] = n; ((int*)(host_out + 48))[1] = sh.last + 1; }
         int* hin = (int*)(host_out + 64);
         for (int e = tid; e < n; e += RF_T) hin[e] = inliers[e];
+        if (done_seq) {
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store((unsigned*)(host_out + 60), done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -740,8 +748,8 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
                                                            const uint8_t* __restrict__ masks, const int* __restrict__ counts,
                                                            int n_hyp, double confidence, double* __restrict__ rt_out,
                                                            int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out,
-                                                           unsigned long long* stamps) {
-    pnp_select_refit_body(obj, img, m, K, models, masks, counts, n_hyp, confidence, rt_out, inliers, info, host_out, stamps);
+                                                           unsigned long long* stamps, unsigned done_seq) {
+    pnp_select_refit_body(obj, img, m, K, models, masks, counts, n_hyp, confidence, rt_out, inliers, info, host_out, stamps, done_seq);
 }
 // batched forms: blockIdx.y = problem (several sequences' PnP calls in one launch), same per-problem arithmetic
 // Two launches per round: hypotheses [0, h0) and [h0, n_hyp). A wavefront of the second launch first replays the sequential RANSAC
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 __global__ __launch_bounds__(RF_T) void k_pnp_select_refit_batch(const PnPProblem* __restrict__ probs) {
     const PnPProblem p = probs[blockIdx.x];
-    pnp_select_refit_body(p.obj, p.img, p.m, p.K, p.models, p.masks, p.counts, p.n_hyp, p.confidence, p.rt_out, p.inliers, p.info, p.host_out, nullptr);
+    pnp_select_refit_body(p.obj, p.img, p.m, p.K, p.models, p.masks, p.counts, p.n_hyp, p.confidence, p.rt_out, p.inliers, p.info, p.host_out, nullptr, 0u);
 }
 
 hipError_t launch_pnp_batch(hipStream_t s, const PnPProblem* d_probs, int n_probs, int max_hyp) {
@@ -790,12 +798,12 @@ hipError_t launch_pnp_batch(hipStream_t s, const PnPProblem* d_probs, int n_prob
 
 hipError_t launch_pnp(hipStream_t s, const float* d_obj, const float* d_img, int m, const double* d_K, const int* d_samples,
                       int n_hyp, float thr, double confidence, double* d_models, uint8_t* d_masks, int* d_counts,
-                      double* d_rt_out, int* d_inliers, int* d_info, char* host_out, unsigned long long* d_stamps) {
+                      double* d_rt_out, int* d_inliers, int* d_info, char* host_out, unsigned long long* d_stamps, unsigned done_seq) {
     { ProfScope ps(K_PNP_HYP, s);
     hipLaunchKernelGGL(k_pnp_hyp, dim3(n_hyp), dim3(64), 0, s, d_obj, d_img, d_samples, d_K, d_models, m, thr, d_masks, d_counts, d_stamps); }
     ProfScope ps3(K_PNP_REFIT, s);
     hipLaunchKernelGGL(k_pnp_select_refit, dim3(1), dim3(RF_T), 0, s, d_obj, d_img, m, d_K, d_models, d_masks, d_counts, n_hyp,
-                       confidence, d_rt_out, d_inliers, d_info, host_out, d_stamps);
+                       confidence, d_rt_out, d_inliers, d_info, host_out, d_stamps, done_seq);
     return hipGetLastError();
 }
 
