@@ -160,7 +160,7 @@ public:
     virtual void ba_solve(double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
                           const int* pt_idx, int n_obs, const double* K, double huber, int max_iterations) = 0;
     void apply(Frame& src) override;
-private:
+protected:
     std::vector<unsigned> seen_epoch;   // per landmark id: the apply() call that last saw it / its index in that call
     std::vector<int> seen_index;
     unsigned epoch_counter = 0;
