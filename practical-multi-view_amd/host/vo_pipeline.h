@@ -80,7 +80,7 @@ public:
                        uint8_t* status, float* err) = 0;
     fmap matchFeatures(Frame& src, Frame& next) override;
 };
-class EPnPSolverBase : public BasePnPSolver {                    // OpenCVEPnPSolver
+class alignas(64) EPnPSolverBase : public BasePnPSolver {                    // OpenCVEPnPSolver
 public:
     OdometryPipeline* tracker = nullptr;
     // cv::solvePnPRansac(obj, img, K, noDist, rvec, tvec, true, 100, 8, .99, inliers); returns false on failure
@@ -96,7 +96,7 @@ void dlt_candidates_host(const double* q1, const double* q2, int n, const double
                          uint8_t* out_mask, int* out_good);
 
 class SpinPool;
-class FivePointTri : public BaseTriangulator {                   // OpenCVFivePointTri
+class alignas(64) FivePointTri : public BaseTriangulator {                   // OpenCVFivePointTri
 public:
     OdometryPipeline* tracker = nullptr;
     int workers = 1;                 // threads evaluating RANSAC hypotheses side by side (results do not depend on it)
@@ -153,7 +153,7 @@ private:
     bool pf_stop = false;
     void prefetch_worker();
 };
-class BundleAdjustmentBase : public BaseOptimizer {              // CeresBundleAdjustment
+class alignas(64) BundleAdjustmentBase : public BaseOptimizer {              // CeresBundleAdjustment
 public:
     OdometryPipeline* tracker = nullptr;
     // ceres::Solve on cams (nc x 6: [aa(R^T), -t]) and pts (np x 3); in place
