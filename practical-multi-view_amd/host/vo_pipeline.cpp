@@ -297,32 +297,17 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
 void BundleAdjustmentBase::apply(Frame& f) {
     const int fn = (int)f.frame + 1;
     const int n = std::min(tracker->cfg.bundle_size, fn);
-    // The work vectors keep their capacity between calls (a solve every other frame would otherwise grow each of them from empty
-    // again), but they are LOCAL objects while in use: push_back through a member writes the adapter object's memory at every
-    // element, and the adapters of the batched leg's 128 sequences sit next to each other on the heap (measured: false sharing cost
-    // 60-100 us of host CPU per frame there).
-    struct Lease {   // take the buffers, give them back at scope exit
-        BundleAdjustmentBase* self;
-        std::vector<int> cam_frame, obs_cam, obs_pt, remap;
-        std::vector<double> tr_opt, obs, p3d_opt, cams_c;
-        std::vector<Feature3D*> p3d_ptr;
-        explicit Lease(BundleAdjustmentBase* s) : self(s) {
-            cam_frame.swap(s->w_cam_frame); obs_cam.swap(s->w_obs_cam); obs_pt.swap(s->w_obs_pt); remap.swap(s->w_remap);
-            tr_opt.swap(s->w_tr_opt); obs.swap(s->w_obs); p3d_opt.swap(s->w_p3d_opt); cams_c.swap(s->w_cams_c); p3d_ptr.swap(s->w_p3d_ptr);
-            cam_frame.clear(); obs_cam.clear(); obs_pt.clear(); remap.clear(); tr_opt.clear(); obs.clear(); p3d_opt.clear(); cams_c.clear(); p3d_ptr.clear();
-        }
-        ~Lease() {
-            cam_frame.swap(self->w_cam_frame); obs_cam.swap(self->w_obs_cam); obs_pt.swap(self->w_obs_pt); remap.swap(self->w_remap);
-            tr_opt.swap(self->w_tr_opt); obs.swap(self->w_obs); p3d_opt.swap(self->w_p3d_opt); cams_c.swap(self->w_cams_c); p3d_ptr.swap(self->w_p3d_ptr);
-        }
-    } w(this);
-    std::vector<int>& cam_frame = w.cam_frame;        // window frames in order (skipping 0)
-    std::vector<double>& tr_opt = w.tr_opt;           // 6 per window frame
-    std::vector<double>& obs = w.obs;                 // 2 per residual block
-    std::vector<int>& obs_cam = w.obs_cam; std::vector<int>& obs_pt = w.obs_pt;
+    // Work vectors: local, sized from the previous solve so that they do not regrow element by element. (Keeping the buffers themselves
+    // between calls was measured and dropped: 6 ms per step for one sequence, but -7 % in the batched leg - 128 sequences x 50 KB of
+    // buffers that are touched every other frame instead of memory the allocator hands straight back to the next gather.)
+    std::vector<int> cam_frame, obs_cam, obs_pt;      // window frames in order (skipping 0); camera / point index per residual block
+    std::vector<double> tr_opt, obs;                  // 6 per window frame; 2 per residual block
+    cam_frame.reserve((size_t)n); tr_opt.reserve((size_t)6 * n);
+    obs.reserve(2 * last_obs + 64); obs_cam.reserve(last_obs + 32); obs_pt.reserve(last_obs + 32);
     const unsigned epoch = ++epoch_counter;   // p3d_index of the reference, as epoch-stamped arrays over the landmark ids
-    std::vector<Feature3D*>& p3d_ptr = w.p3d_ptr;     // (raw: nothing erases a landmark between the gather and the update below; one thread)
-    std::vector<double>& p3d_opt = w.p3d_opt;
+    std::vector<Feature3D*> p3d_ptr;                  // (raw: nothing erases a landmark between the gather and the update below; one thread)
+    std::vector<double> p3d_opt;
+    p3d_ptr.reserve(last_points + 32); p3d_opt.reserve(3 * last_points + 96);
     HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[2]);
     std::vector<std::shared_ptr<Frame>> window((size_t)n);   // snapshot under the lock: the front-end thread may be appending
     {
@@ -364,9 +349,10 @@ void BundleAdjustmentBase::apply(Frame& f) {
     }
     const int n_obs = (int)obs_cam.size();
     // Only parameter blocks that appear in a residual block are part of the Ceres problem: compact the cameras.
-    std::vector<int>& remap = w.remap;
-    remap.assign(cam_frame.size(), -1);
-    std::vector<double>& cams_c = w.cams_c;
+    last_obs = (size_t)n_obs; last_points = p3d_ptr.size();
+    std::vector<int> remap(cam_frame.size(), -1);
+    std::vector<double> cams_c;
+    cams_c.reserve(tr_opt.size());
     int nc = 0;
     {
         std::vector<uint8_t> used(cam_frame.size(), 0);

@@ -164,9 +164,7 @@ protected:
     std::vector<unsigned> seen_epoch;   // per landmark id: the apply() call that last saw it / its index in that call
     std::vector<int> seen_index;
     unsigned epoch_counter = 0;
-    std::vector<int> w_cam_frame, w_obs_cam, w_obs_pt, w_remap;   // work vectors of apply(), kept between calls
-    std::vector<double> w_tr_opt, w_obs, w_p3d_opt, w_cams_c;
-    std::vector<Feature3D*> w_p3d_ptr;
+    size_t last_obs = 0, last_points = 0;   // sizes of the previous solve: reserve() for the next
 };
 
 // optional section timers of the host adapters (PMV_HOST_PROF=1 prints them to stderr at the end of a run)
