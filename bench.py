@@ -405,7 +405,7 @@ def main():
                    host_cores_visible=os.cpu_count(),
                    sample=f"first {m} of {frames.shape[0]} frames of the same sequence; oracle pipeline (speed-oriented twins, bit-identical to the plain "
                           f"restatement): front-end + back-end threads, LK over {nthr} pooled threads, grid cells side by side, BA residuals on 4 threads, "
-                          f"five-point RANSAC over {min(nthr, 8)}",
+                          f"two-view geometry ahead of time on 2 helper threads (five-point RANSAC over {min(nthr, 8)} when computed inline)",
                    seconds=round(dt, 3), wall_seconds=round(dt_wall, 3), features_identical_to_gpu_run=bool(feats_same),
                    poses_agree_1e6_until_frame=int(bad[0]) if len(bad) else int(len(o.poses)),
                    stage_seconds={k_: round(float(o.stats[k_]), 3) for k_ in ("t_lk", "t_detect", "t_pnp", "t_tri", "t_ba")})
