@@ -58,6 +58,7 @@ struct BAArgs {
     int ldw, krows, tiles_r, tiles_c, kslices, kper, gp_rows;
     unsigned long long* stamps;   // optional (diagnostic): 32 accumulated shader-clock phase timers
     double* out;                  // optional: host-mapped result block [summary 8 | cams 6*nc | pts 3*np] (multi-kernel LM)
+    unsigned done_seq;            // != 0 (with `out`): the finish kernel stores it last into the low word of summary slot 7 (the host spins on it)
 };
 
 hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* pts, const double* obs, const int* cam_idx,

@@ -371,6 +371,7 @@ int pmv::ba_prepare(pmv_ctx* ctx, BackendBuffers* b, const double* cams, int nc,
     A.Einv = b->d_Einv; A.gp = b->d_gp; A.Yd = b->d_Yd; A.Wd = b->d_Wd; A.S = b->d_S; A.rhs = b->d_rhs; A.Gpart = b->d_Gpart; A.summary = d_sum;
     A.stamps = stamps_on() ? b->d_stamps : nullptr;
     A.out = nullptr;
+    A.done_seq = 0;
     A.tiles_r = tiles_r; A.tiles_c = tiles_c;
     A.ldw = A.tiles_c * 16;
     A.krows = round_up(3 * np, 16);
@@ -445,15 +446,35 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     rc = ba_prepare(ctx, b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber_delta, max_iterations, !single, &A, &io_bytes);
     if (rc) return rc;
     char* hs = (char*)b->h_stage;
-    CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
     static const bool check = getenv("PMV_BA_CHECK") != nullptr;
+    // multi-kernel chain: the finish kernel writes the result into hs and, last, this call's sequence number into the low word of summary
+    // slot 7; the result is read as soon as that store lands (PMV_BACK_WAIT=sync: hipStreamSynchronize instead; see pmv_pnp_ransac)
+    static const bool flag_wait_env = !(getenv("PMV_BACK_WAIT") && !strcmp(getenv("PMV_BACK_WAIT"), "sync"));
+    const bool flag_wait = flag_wait_env && !single && !check;
+    volatile unsigned* done_word = (volatile unsigned*)((double*)hs + 7);
+    if (flag_wait) {
+        if (++b->done_seq == 0) b->done_seq = 1;
+        ((double*)hs)[7] = 0.0;
+        A.done_seq = b->done_seq;
+    }
+    CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
     std::vector<char> saved;
     if (check) saved.assign(hs, hs + io_bytes);
     if (single) CKC(launch_ba_lm(s, A));
     else CKC(launch_ba_multi(s, A, b->d_bastate, b->d_bapart));
     const size_t out_bytes = (8 + (size_t)nc * 6 + (size_t)np * 3) * 8;
     if (single) CKC(hipMemcpyAsync(hs, b->d_ba_io, out_bytes, hipMemcpyDeviceToHost, s));   // (multi: the finish kernel wrote into hs)
-    CKC(hipStreamSynchronize(s));
+    if (flag_wait) {
+        (void)hipStreamQuery(s);   // lets the runtime retire the commands of earlier calls while the GPU works on this one
+        for (unsigned spins = 1;; spins++) {
+            if (__atomic_load_n(done_word, __ATOMIC_ACQUIRE) == b->done_seq) break;
+            if ((spins & 0xffffu) == 0) {   // a faulted launch never signals: ask the runtime now and then
+                const hipError_t e = hipStreamQuery(s);
+                if (e != hipSuccess && e != hipErrorNotReady) CKC(e);
+            }
+            __builtin_ia32_pause();
+        }
+    } else CKC(hipStreamSynchronize(s));
     const double* h_out = (const double*)hs;
     if (!single && check) {   // diagnostic: the same problem through the one-workgroup kernel, differences to stderr
         std::vector<double> got(h_out, h_out + out_bytes / 8);

@@ -1525,6 +1525,11 @@ __device__ inline void bam_finish_role(const BAArgs& A, const BAGState* __restri
         osum[0] = ss.initial_cost; osum[1] = ss.x_cost; osum[2] = ss.iter; osum[3] = ss.successful;
         osum[4] = ss.termination;
     }
+    if (A.out && A.done_seq) {   // the result block is complete: publish this call's sequence number (see pmv_ba_solve)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store((unsigned*)(A.out + 7), A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ __launch_bounds__(BM_T) void k_bam_finish(BAArgs A, const BAGState* st_in, const double* part4, int nbp) {
