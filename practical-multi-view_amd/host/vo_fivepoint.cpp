@@ -615,11 +615,15 @@ void FivePointTri::prefetch_worker() {
     }
 }
 
-FivePointTri::~FivePointTri() {
-    { std::lock_guard<std::mutex> lk(pf_mu); pf_stop = true; }
+void FivePointTri::finish() {
+    { std::lock_guard<std::mutex> lk(pf_mu); pf_stop = true; pf_queue.clear(); pf_jobs.clear(); }
     pf_cv.notify_all();
     for (auto& t : pf_threads) t.join();
+    pf_threads.clear();
+    { std::lock_guard<std::mutex> lk(pf_mu); pf_stop = false; }   // (a later run on the same object starts its helpers again)
 }
+
+FivePointTri::~FivePointTri() { finish(); }
 
 // ---- OpenCVFivePointTri.cpp:5-54 ---------------------------------------------------------------------------------
 void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {

@@ -645,6 +645,7 @@ void OdometryPipeline::run_threaded() {
     { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_one(); }
     stats.hp.t[10] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_front0).count();
     back.join();
+    if (triangulator) triangulator->finish();   // helper threads of the two-view prefetch: none survives the run
     if (front_error) std::rethrow_exception(front_error);
     if (back_error) std::rethrow_exception(back_error);
 }

@@ -108,6 +108,7 @@ public:
     // has started it). Same function on the same points: identical E, mask and iteration count. Off for the hook form.
     int prefetch_threads = 0;
     void prefetch(const Frame& prev) override;
+    void finish() override;   // stops and joins the helper threads (jobs nobody asked for are dropped): nothing of this run touches the plugin hooks afterwards
     ~FivePointTri() override;
     // optional kernel hook for the RANSAC hypotheses of findEssentialMat: for n_hyp samples (5 indices each) of the n normalised
     // correspondences return the essential matrices of every sample (models: n_hyp x 90, n_models: n_hyp) and their inlier counts

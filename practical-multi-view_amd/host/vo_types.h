@@ -253,6 +253,8 @@ public:
     // just tracked) is final. A triangulator may start whatever depends on nothing but these correspondences; the back-end reaches
     // this frame pair at least one frame later. Default: nothing.
     virtual void prefetch(const Frame& prev) { (void)prev; }
+    // End of the run (both pipeline threads are done): whatever prefetch() started must be finished or dropped before this returns.
+    virtual void finish() {}
 };
 class BaseOptimizer {
 public:
