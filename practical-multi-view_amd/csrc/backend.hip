@@ -9,6 +9,13 @@
 
 namespace pmv {
 
+// Input block of a solve from mapped pinned host memory into HBM: a copy launch on the solve's own stream instead of a DMA-engine
+// transfer (hipMemcpyAsync of ~50 KB goes through SDMA: 10-15 us until the first kernel of the chain may start; this is ~5).
+__global__ __launch_bounds__(256) void k_stage_block(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned n16) {
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 int backend_alloc(pmv_ctx* c, BackendBuffers** out) {
@@ -213,7 +220,12 @@ int pmv_pnp_ransac(pmv_ctx* ctx, const float* obj_xyz, const float* img_xy, int 
     PnPProblem P;
     size_t in_bytes = 0;
     pnp_prepare(b, obj_xyz, img_xy, m, K, iterations, reproj_err, confidence, &P, &in_bytes);
-    CKC(hipMemcpyAsync(b->d_pnp_in, b->h_stage, in_bytes, hipMemcpyHostToDevice, s));
+    static const bool stage_by_kernel = !(getenv("PMV_BA_STAGE") && !strcmp(getenv("PMV_BA_STAGE"), "dma"));
+    if (stage_by_kernel) {
+        const unsigned n16 = (unsigned)((in_bytes + 15) >> 4);
+        hipLaunchKernelGGL(k_stage_block, dim3(std::min(8u, (n16 + 255u) / 256u)), dim3(256), 0, s, (const uint4*)b->d_h_stage, (uint4*)b->d_pnp_in, n16);
+        CKC(hipGetLastError());
+    } else CKC(hipMemcpyAsync(b->d_pnp_in, b->h_stage, in_bytes, hipMemcpyHostToDevice, s));
     // the refit kernel writes [rt | info | inliers] straight into the pinned block and, last, this call's sequence number into the
     // block's fourth info word: the result is read as soon as that store lands (PMV_BACK_WAIT=sync: hipStreamSynchronize instead)
     static const bool flag_wait = !(getenv("PMV_BACK_WAIT") && !strcmp(getenv("PMV_BACK_WAIT"), "sync"));
@@ -457,7 +469,12 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
         ((double*)hs)[7] = 0.0;
         A.done_seq = b->done_seq;
     }
-    CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
+    static const bool stage_by_kernel = !(getenv("PMV_BA_STAGE") && !strcmp(getenv("PMV_BA_STAGE"), "dma"));
+    if (stage_by_kernel && !check) {   // (h_stage and d_ba_io are 16-byte aligned and have >= 16 B of slack)
+        const unsigned n16 = (unsigned)((io_bytes + 15) >> 4);
+        hipLaunchKernelGGL(k_stage_block, dim3(std::min(64u, (n16 + 255u) / 256u)), dim3(256), 0, s, (const uint4*)b->d_h_stage, (uint4*)b->d_ba_io, n16);
+        CKC(hipGetLastError());
+    } else CKC(hipMemcpyAsync(b->d_ba_io, hs, io_bytes, hipMemcpyHostToDevice, s));
     std::vector<char> saved;
     if (check) saved.assign(hs, hs + io_bytes);
     if (single) CKC(launch_ba_lm(s, A));
