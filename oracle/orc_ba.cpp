@@ -65,8 +65,9 @@ static inline void huber_rho(double s, double a, double rho[3]) {
 // Optional worker threads for the residual/Jacobian evaluation (bench.py's cpu_baseline leg: CeresBundleAdjustment.cpp:58
 // num_threads = 4). Observations are independent; the per-observation cost terms are added in observation order afterwards, so
 // the result does not depend on the thread count.
-static Pool* g_ba_pool = nullptr;
-static int g_ba_threads = 1;
+// (thread-local: set by the thread that calls ba_solve, so several oracle pipelines can run side by side in one process)
+static thread_local Pool* g_ba_pool = nullptr;
+static thread_local int g_ba_threads = 1;
 void ba_set_pool(Pool* pool, int threads) { g_ba_pool = pool; g_ba_threads = pool ? std::max(1, threads) : 1; }
 
 // cost = 1/2 sum rho(||r||^2); optionally corrected residuals (2*nobs) and Jacobians (nobs*18: Jc 12, Jp 6)

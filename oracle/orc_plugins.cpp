@@ -8,6 +8,8 @@
 #include "orc_fast.h"
 #include "vo_capi_impl.h"
 #include <cstring>
+#include <cstdlib>
+#include <stdexcept>
 
 namespace {
 using namespace vo;
@@ -91,9 +93,15 @@ struct CpuPnP : EPnPSolverBase {
     }
 };
 struct CpuBA : BundleAdjustmentBase {
+    orc::Pool* pool = nullptr;   // fast mode: residual evaluation on 4 threads (CeresBundleAdjustment.cpp:58), this run's own pool
+    int calls = 0;
     void ba_solve(double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx, const int* pt_idx, int n_obs,
                   const double* K, double huber, int max_iterations) override {
         orc::BASummary s;
+        // test hook: ORC_FAIL_BA_CALL=k makes the k-th solve of a run throw, like a capacity error of a device plugin would (the
+        // error path of OdometryPipeline::run_threaded has no other way to be exercised on the CPU)
+        if (const char* e = getenv("ORC_FAIL_BA_CALL")) if (++calls == atoi(e)) throw std::runtime_error("oracle: forced BA failure (ORC_FAIL_BA_CALL)");
+        orc::ba_set_pool(pool, 4);   // per calling thread: the back-end thread of THIS pipeline
         orc::ba_solve(cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, &s);
     }
 };
@@ -106,23 +114,28 @@ void* orc_pipeline_run(const vo::PipelineParams* P, const uint8_t* frames, const
     // reserved bit 0 = "fast": the speed-oriented twins of orc_fast.cpp (bench.py's cpu_baseline); results are bit-identical
     // (two pools: a Pool serves one caller at a time, and the front-end and back-end threads run concurrently)
     std::unique_ptr<orc::Pool> pool, ba_pool;
-    if (P->reserved & 1) { pool.reset(new orc::Pool(std::max(0, P->n_threads - 1))); ba_pool.reset(new orc::Pool(3)); }
+    // (n_threads == 1 in fast mode: no helper threads at all - the single-thread form bench.py runs 16 of side by side)
+    if (P->reserved & 1) { pool.reset(new orc::Pool(std::max(0, P->n_threads - 1))); if (P->n_threads > 1) ba_pool.reset(new orc::Pool(std::min(3, P->n_threads - 1))); }
     vo::BaseFeatureExtractor* ex;
     if (P->extractor == 1) ex = new CpuShiTomasi(); else if (P->extractor == 2) ex = new CpuFast(); else { auto* g = new CpuGftt(); g->pool = pool.get(); ex = g; }
     run->owned_ex.push_back(ex);
     vo::BaseFeatureMatcher* lk;
     if (P->matcher == 1) { auto* k = new CpuKnn(); k->extractor = ex; lk = k; }
     else { auto* l = new CpuLK(); l->nthreads = P->n_threads; l->pool = pool.get(); lk = l; }
-    // the back-end thread evaluates BA residuals on 4 threads of the same pool (CeresBundleAdjustment.cpp:58)
-    orc::ba_set_pool(ba_pool.get(), 4);
     auto* pnp = new CpuPnP(); pnp->tracker = &run->pipe;
     auto* tri = new vo::FivePointTri(); tri->tracker = &run->pipe; tri->workers = std::max(1, std::min(P->n_threads, 8));
     tri->prefetch_threads = P->n_threads > 1 ? 2 : 0;   // same host code as the product: essential matrices ahead of time
-    auto* ba = new CpuBA(); ba->tracker = &run->pipe;
+    auto* ba = new CpuBA(); ba->tracker = &run->pipe; ba->pool = ba_pool.get();
     run->m = lk; run->p = pnp; run->tr = tri; run->b = ba;
     run->pipe.extractor = ex; run->pipe.matcher = lk; run->pipe.pnpsolver = pnp; run->pipe.triangulator = tri; run->pipe.ba = ba;
-    vo::pipeline_execute(*run, *P);
+    try {
+        vo::pipeline_execute(*run, *P);
+    } catch (const std::exception&) {   // a plugin error ended the run (both pipeline threads are joined by then): no result
+        delete run;
+        return nullptr;
+    }
     orc::ba_set_pool(nullptr, 1);
+    ba->pool = nullptr;   // the pools end with this call
     return run;
 }
 void orc_pipeline_free(void* h) { delete (vo::PipelineRun*)h; }

@@ -67,7 +67,7 @@ int backend_alloc(pmv_ctx* c, BackendBuffers** out) {
     b->h_stage_bytes = std::max(b->h_stage_bytes, b->tri_in_bytes + b->tri_out_bytes);
     b->h_stage_bytes = std::max(b->h_stage_bytes, b->tri_in_bytes + (size_t)FP_MAX_HYP * (90 * 8 + 44) + 256);   // five-point round in + out
     (void)hipHostFree(b->h_stage);
-    CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes, hipHostMallocMapped));
+    CKB(hipHostMalloc(&b->h_stage, b->h_stage_bytes, hipHostMallocMapped | hipHostMallocCoherent));
     CKB(hipHostGetDevicePointer((void**)&b->d_h_stage, b->h_stage, 0));
     {   // every buffer a kernel may touch exists (a missed allocation must fail here, not as a GPU fault later)
         const void* must[] = {b->d_x, b->d_cand, b->d_scale, b->d_diag, b->d_D2, b->d_step, b->d_res, b->d_J, b->d_Einv, b->d_gp, b->d_Yd, b->d_Wd,

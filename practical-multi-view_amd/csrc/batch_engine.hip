@@ -59,7 +59,7 @@ struct Growable {   // device (or mapped pinned host) buffer that only grows; de
         if (need <= cap) return hipSuccess;
         if (p) { hipError_t e = host ? hipHostFree(p) : hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
         need = (need * 5 / 4 + 4095) & ~(size_t)4095;
-        hipError_t e = host ? hipHostMalloc(&p, need, hipHostMallocMapped) : hipMalloc(&p, need);
+        hipError_t e = host ? hipHostMalloc(&p, need, hipHostMallocMapped | hipHostMallocCoherent) : hipMalloc(&p, need);
         if (e != hipSuccess) return e;
         cap = need;
         dev = (char*)p;
@@ -238,15 +238,17 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     hipStream_t s = C.s;
     std::vector<DetReq*> det;
     for (Req* r : batch) det.push_back((DetReq*)r);
-    PyrLayout L = ctx->slot_layout[det[0]->slot];
-    // ---- detectors: requests with the same parameters share a launch (cells of several frames)
-    struct Group { int kind, max_per_cell, unlimited; double quality, min_dist; std::vector<DetReq*> reqs; int n_cells = 0; size_t out_off = 0; };
+    // ---- detectors: requests with the same parameters AND the same frame geometry share a launch (cells of several frames); the
+    // geometry is the one actually staged in each request's slot (KITTI 00-02, 03 and 04-10 have three different sizes)
+    struct Group { int kind, max_per_cell, unlimited; double quality, min_dist; PyrLayout L; std::vector<DetReq*> reqs; int n_cells = 0; size_t out_off = 0; };
     std::vector<Group> groups;
     for (DetReq* r : det) {
+        const PyrLayout& Lr = ctx->slot_layout[r->slot];
         Group* g = nullptr;
         for (Group& x : groups)
-            if (x.kind == r->kind && x.max_per_cell == r->max_per_cell && x.unlimited == r->unlimited && x.quality == r->quality && x.min_dist == r->min_dist) { g = &x; break; }
-        if (!g) { groups.push_back(Group{r->kind, r->max_per_cell, r->unlimited, r->quality, r->min_dist, {}, 0, 0}); g = &groups.back(); }
+            if (x.kind == r->kind && x.max_per_cell == r->max_per_cell && x.unlimited == r->unlimited && x.quality == r->quality && x.min_dist == r->min_dist &&
+                x.L.w[0] == Lr.w[0] && x.L.h[0] == Lr.h[0] && x.L.n_levels == Lr.n_levels) { g = &x; break; }
+        if (!g) { groups.push_back(Group{r->kind, r->max_per_cell, r->unlimited, r->quality, r->min_dist, Lr, {}, 0, 0}); g = &groups.back(); }
         r->cell_base = g->n_cells;
         g->n_cells += r->n_cells;
         g->reqs.push_back(r);
@@ -275,10 +277,10 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
             double* dsc = (double*)(dd + tot_out * 8) + g.out_off;
             int* dcnt = (int*)(dd + tot_out * 16) + c0;
             if (g.kind == 1)
-                EK(launch_gftt(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, g.min_dist, g.unlimited, (float*)C.d_eig.p + c0 * CELL_PIX,
+                EK(launch_gftt(s, ctx->d_slots, g.L, dc, g.n_cells, g.max_per_cell, g.quality, g.min_dist, g.unlimited, (float*)C.d_eig.p + c0 * CELL_PIX,
                                (unsigned*)C.d_cellmax.p + c0, dxy, dcnt, C.d_flags, (unsigned*)C.d_spill.p + c0 * CELL_PIX));
             else
-                EK(launch_shitomasi(s, ctx->d_slots, L, dc, g.n_cells, g.max_per_cell, g.quality, (double*)C.d_eig.p + c0 * CELL_PIX,
+                EK(launch_shitomasi(s, ctx->d_slots, g.L, dc, g.n_cells, g.max_per_cell, g.quality, (double*)C.d_eig.p + c0 * CELL_PIX,
                                     (unsigned long long*)C.d_cellmax.p + c0, dxy, dsc, dcnt, C.d_flags, (unsigned*)C.d_spill.p + c0 * CELL_PIX));
             c0 += g.n_cells;
         }
@@ -526,13 +528,13 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
             // frames/s at B = 64 - the PnP hypotheses need the whole chip; equal priorities: no difference either)
             CKC(hipStreamCreateWithPriority(&C.s, hipStreamNonBlocking, prio));
             CKC(hipEventCreateWithFlags(&C.ev, hipEventBlockingSync | hipEventDisableTiming));
-            CKC(hipHostMalloc(&C.h_done, 64, hipHostMallocMapped));
+            CKC(hipHostMalloc(&C.h_done, 64, hipHostMallocMapped | hipHostMallocCoherent));
             *C.h_done = 0;
             CKC(hipHostGetDevicePointer((void**)&C.dm_done, C.h_done, 0));
             if (r == R_LK) {
-                CKC(hipHostMalloc(&C.h_out_xy, E->cap_tracks * 8, hipHostMallocMapped));
-                CKC(hipHostMalloc(&C.h_status, E->cap_tracks, hipHostMallocMapped));
-                CKC(hipHostMalloc(&C.h_err, E->cap_tracks * 4, hipHostMallocMapped));
+                CKC(hipHostMalloc(&C.h_out_xy, E->cap_tracks * 8, hipHostMallocMapped | hipHostMallocCoherent));
+                CKC(hipHostMalloc(&C.h_status, E->cap_tracks, hipHostMallocMapped | hipHostMallocCoherent));
+                CKC(hipHostMalloc(&C.h_err, E->cap_tracks * 4, hipHostMallocMapped | hipHostMallocCoherent));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_out_xy, C.h_out_xy, 0));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_status, C.h_status, 0));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_err, C.h_err, 0));

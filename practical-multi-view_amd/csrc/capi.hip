@@ -11,11 +11,21 @@ using namespace pmv;
 static thread_local char g_create_err[512] = "";
 thread_local pmv::Profiler* pmv::tl_prof = nullptr;
 
+// The message goes to the calling thread's own buffer first (what ck() of hip_pipeline.hip and the batch engine's sequence threads
+// report: a failing sequence must not pick up another sequence's text) and then, under a mutex, to the context's buffer that
+// pmv_last_error() hands to the caller of the entry point.
+static thread_local char tl_err[512] = "";
+const char* pmv::thread_error() { return tl_err; }
 void pmv::set_err(pmv_ctx* c, const char* fmt, ...) {
+    char tmp[512];   // (the arguments may point into tl_err or c->err themselves)
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(c ? c->err : g_create_err, 512, fmt, ap);
+    vsnprintf(tmp, sizeof(tmp), fmt, ap);
     va_end(ap);
+    memcpy(tl_err, tmp, sizeof(tmp));
+    if (!c) { memcpy(g_create_err, tmp, sizeof(tmp)); return; }
+    std::lock_guard<std::mutex> lk(c->err_mu);
+    memcpy(c->err, tmp, sizeof(tmp));
 }
 
 PyrLayout pmv::make_layout(int w, int h) {
@@ -81,9 +91,9 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     CK(hipMalloc(&c->d_status, nt)); CK(hipMalloc(&c->d_err, nt * 4));
     CK(hipHostMalloc(&c->h_prev_xy, nt * 12 + 64));
     // LK results: 13 bytes per track, written by the kernel through the device aliases of these mapped pinned buffers (no D2H copies)
-    CK(hipHostMalloc(&c->h_out_xy, nt * 8, hipHostMallocMapped));
-    CK(hipHostMalloc(&c->h_status, nt, hipHostMallocMapped));
-    CK(hipHostMalloc(&c->h_err, nt * 4, hipHostMallocMapped));
+    CK(hipHostMalloc(&c->h_out_xy, nt * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipHostMalloc(&c->h_status, nt, hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipHostMalloc(&c->h_err, nt * 4, hipHostMallocMapped | hipHostMallocCoherent));
     CK(hipHostGetDevicePointer((void**)&c->dm_out_xy, c->h_out_xy, 0));
     CK(hipHostGetDevicePointer((void**)&c->dm_status, c->h_status, 0));
     CK(hipHostGetDevicePointer((void**)&c->dm_err, c->h_err, 0));

@@ -15,7 +15,7 @@ namespace {
 using namespace vo;
 
 struct HipError : std::runtime_error { int code; HipError(int c, const char* m) : std::runtime_error(m), code(c) {} };
-inline void ck(pmv_ctx* ctx, int rc) { if (rc != PMV_OK) throw HipError(rc, pmv_last_error(ctx)); }
+inline void ck(pmv_ctx* ctx, int rc) { (void)ctx; if (rc != PMV_OK) throw HipError(rc, pmv::thread_error()); }   // this thread's own message
 
 static void cells_of(const std::vector<ImageView>& cells, std::vector<int>& out) {
     out.clear();
@@ -293,6 +293,14 @@ int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* param
         if (P.bundle_size != 0 && P.bundle_size < 3) { pmv::set_err(ctx, "pmv_pipeline_run_batch: bundle_size 1..2 divides by zero in the reference"); return PMV_ERR_INVALID; }
         if (P.bundle_size > ctx->max_ba_cams) { pmv::set_err(ctx, "pmv_pipeline_run_batch: bundle_size exceeds max_ba_cams"); return PMV_ERR_CAPACITY; }
         if (P.w != params[0].w || P.h != params[0].h) { pmv::set_err(ctx, "pmv_pipeline_run_batch: all sequences must share the frame size"); return PMV_ERR_INVALID; }
+        for (int i = 0; i < P.n_frames; i++) {   // the geometry actually staged in the slots, not only the parameter structs
+            const pmv::PyrLayout& Ls = ctx->slot_layout[first_slot[b] + i];
+            if (Ls.n_levels == 0 || Ls.w[0] != P.w || Ls.h[0] != P.h) {
+                pmv::set_err(ctx, "pmv_pipeline_run_batch: sequence %d: slot %d holds %s (%dx%d), the run is %dx%d", b, first_slot[b] + i,
+                             Ls.n_levels == 0 ? "no frame" : "a frame of another size", Ls.w[0], Ls.h[0], P.w, P.h);
+                return PMV_ERR_INVALID;
+            }
+        }
         if (P.matcher != 0 || P.extractor > 1) { pmv::set_err(ctx, "pmv_pipeline_run_batch: the batch engine serves the reference's default plugins (LK; GFTT or ShiTomasi)"); return PMV_ERR_INVALID; }
     }
     pmv::BatchEngine* eng = nullptr;

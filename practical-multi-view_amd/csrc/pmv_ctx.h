@@ -60,11 +60,13 @@ struct pmv_ctx {
     pmv::Ingest* ingest = nullptr;      // non-null while a pmv_frames_stream_begin .. _end bracket is open
     pmv::Profiler prof;
     pmv_call_log log;
+    std::mutex err_mu;                  // set_err from several host threads (batch engine)
     char err[512] = "";
 };
 
 namespace pmv {
 void set_err(pmv_ctx* c, const char* fmt, ...);
+const char* thread_error();         // the last message set_err wrote on the calling thread
 PyrLayout make_layout(int w, int h);
 int backend_create(pmv_ctx* c);     // allocates PnP/BA workspaces
 void backend_destroy(pmv_ctx* c);

@@ -583,6 +583,9 @@ void OdometryPipeline::run_threaded() {
             }
         } catch (...) {
             back_error = std::current_exception();
+            // under the pipe's mutex: the front-end evaluates `failed` in its wait predicate with the lock held, so the store cannot
+            // fall between its test and its sleep (a notify without the lock could: the dead back-end never pops a job again)
+            std::lock_guard<std::mutex> lk(mu);
             failed.store(true);
             cv_space.notify_all();
         }

@@ -21,6 +21,33 @@ def assign_sequences(lengths, world):
     return ranks
 
 
+def cut(lengths, L, min_len=8):
+    """Cut every sequence into independent SUBSEQUENCES of L frames (the reference's own loop makes a subsequence
+    "just a shorter run": OdometryPipeline.cpp:212-229 reads images init_offset+1 .. stop, :428-482 `initialise` picks the start
+    among the first init_frames images of whatever list it is given). Piece p of sequence s covers images [start, start + n) of
+    s and is a complete run of its own: own initialise, own landmarks, poses relative to its own first pose. A tail shorter
+    than min_len (a run needs init_frames + 2 images) is merged into the piece before it. L <= 0: no cutting.
+    Returns [(sequence id, start, n)] in (sequence, start) order."""
+    pieces = []
+    for sid, n in enumerate(lengths):
+        if L <= 0 or n <= L:
+            pieces.append((sid, 0, n))
+            continue
+        starts = list(range(0, n, L))
+        if n - starts[-1] < min_len:
+            starts.pop()
+        for i, st in enumerate(starts):
+            end = starts[i + 1] if i + 1 < len(starts) else n
+            pieces.append((sid, st, end - st))
+    return pieces
+
+
+def assign_pieces(pieces, world):
+    """Longest-first greedy dealing of cut() pieces to ranks: ranks[r] = pieces of rank r in processing order (longest first)."""
+    a = assign_sequences([p[2] for p in pieces], world)
+    return [[pieces[i] for i in idx] for idx in a]
+
+
 def gather_poses(dist, poses, max_frames, device=None):
     """all-gather of variable-length pose arrays. poses: (n_i, 12) float64 numpy on every rank.
     Returns a list (one entry per rank) of (n_r, 12) numpy arrays, identical on every rank."""

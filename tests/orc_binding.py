@@ -135,13 +135,13 @@ class PipelineParams(C.Structure):
 class PipelineResult:
     """poses (n,12: R row-major then t), per-frame feature triples (col,row,landmark) in container order, stats"""
 
-    def __init__(self, lib, prefix, handle):
+    def __init__(self, lib, prefix, handle, want_features=True):
         g = lambda name: getattr(lib, prefix + name)
         n = g("num_poses")(handle)
         self.poses = np.zeros((n, 12), np.float64)
         if n:
             g("get_poses")(handle, _p(self.poses, _f64p))
-        nf = g("num_frames")(handle)
+        nf = g("num_frames")(handle) if want_features else 0
         self.features = []
         for k in range(nf):
             c = g("frame_feature_count")(handle, k)
@@ -158,7 +158,7 @@ class PipelineResult:
 
 
 def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, bundle_size=5, ba_iterations=5,
-                 extractor=0, threaded=0, n_threads=1, fast=False, lib=None, matcher=0):
+                 extractor=0, threaded=0, n_threads=1, fast=False, lib=None, matcher=0, want_features=True):
     """the oracle pipeline; fast=True: the speed-oriented twins (orc_fast.cpp; identical results), lib: another build of the
     same sources (bench.py times oracle/liborc_fast.so, built -O3 -march=native on the machine it runs on)"""
     o = load()
@@ -178,7 +178,9 @@ def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, b
     gt = np.ascontiguousarray(gt_poses, np.float64).reshape(n, 12)
     lib.orc_pipeline_run.argtypes = [C.POINTER(PipelineParams), _u8p, _f64p, _f64p]
     hnd = lib.orc_pipeline_run(C.byref(P), _p(frames, _u8p), _p(Kd, _f64p), _p(gt, _f64p))
-    res = PipelineResult(lib, "orc_pipeline_", hnd)
+    if not hnd:
+        raise RuntimeError("orc_pipeline_run: a plugin error ended the run")
+    res = PipelineResult(lib, "orc_pipeline_", hnd, want_features)
     lib.orc_pipeline_free(hnd)
     return res
 

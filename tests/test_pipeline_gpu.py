@@ -206,6 +206,37 @@ def test_config5_eight_sequences_sharded_one_per_rank(pmv, gpu_ctx_factory):
         _compare(single[sid], o, 1e-6, min_tight=min(MIN_TIGHT, len(o.poses)))
 
 
+def test_subsequences_are_independent_runs_over_their_image_range(pmv, gpu_ctx_factory):
+    """SURVEY §8e / sharding.cut: a long sequence staged ONCE in HBM is cut into subsequences; each is run through the batch engine
+    straight from its slot range [start, start + n) of the long sequence. Every subsequence must be bitwise equal to its own single
+    run (the same images staged alone at slot 0 of another context) and agree with the oracle's run over the same image range:
+    features bit-exact, poses to the end-to-end bar. (The reference's loop makes a subsequence "just a shorter run":
+    OdometryPipeline.cpp:212-229 reads the image list it is given, :428-482 initialise picks the start among its first frames.)"""
+    import importlib
+    sh = importlib.import_module("practical-multi-view_amd.sharding")
+    cfg, n_long, L = K00, 150, 48
+    frames, gt = pmv.synth_sequence(1005, 0, n_long, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16)
+    K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+    pieces = sh.cut([n_long], L, min_len=8)
+    assert pieces == [(0, 0, 48), (0, 48, 48), (0, 96, 54)]          # the 6-frame tail joins the last piece
+    big = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n_long, max_tracks=1024, max_ba_cams=8, max_ba_points=4096, max_ba_obs=32768)
+    big.frames_stage(0, frames)
+    got = big.pipeline_run_batch([(st, n, gt[st: st + n]) for _, st, n in pieces], cfg["w"], cfg["h"], K, threaded=0)
+    one = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=max(n for _, _, n in pieces), max_tracks=4096)
+    for (_, st, n), g in zip(pieces, got):
+        one.frames_stage(0, frames[st: st + n])
+        s = one.pipeline_run(n, cfg["w"], cfg["h"], K, gt[st: st + n], threaded=1, n_threads=2)
+        assert np.array_equal(g.poses, s.poses), f"subsequence at {st} differs from its single run"
+        assert len(g.features) == len(s.features) and all(np.array_equal(a, b) for a, b in zip(g.features, s.features))
+        assert np.array_equal(g.poses[0], np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0.0]))     # its own start pose
+        o = ob.run_pipeline(frames[st: st + n], K, gt[st: st + n], threaded=1, n_threads=8)
+        print(f"subsequence [{st}, {st + n}):", end=" ")
+        _compare(g, o, 1e-6)
+    # and the generator gives the same images for a piece rendered on its own (what bench.py --config 5 --subseq does per rank)
+    f2, g2 = pmv.synth_sequence(1005, 48, 48, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16)
+    assert np.array_equal(f2, frames[48:96]) and np.array_equal(g2, gt[48:96])
+
+
 def test_streamed_ingest_is_bit_identical_to_staged_frames(pmv, gpu_ctx_factory):
     """frames handed over in HOST memory and streamed into HBM chunk by chunk (ingest thread, third stream, pyramids
     per chunk) while the pipeline is already tracking give the same features and poses as pmv_frames_stage + a run with all
@@ -256,6 +287,15 @@ def test_plugin_error_in_the_backend_thread_is_returned_not_fatal(pmv, gpu_ctx_f
     with pytest.raises(pmv.PmvError) as e:
         ctx.pipeline_run_batch([(0, n, poses)], cfg["w"], cfg["h"], K)
     assert e.value.code == -3
+    # a one-job pipe: the front-end is blocked on a full pipe when the back-end dies - it must be woken, not left waiting
+    import os
+    os.environ["PMV_PIPE_DEPTH"] = "1"
+    try:
+        with pytest.raises(pmv.PmvError) as e:
+            ctx.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1)
+        assert e.value.code == -3
+    finally:
+        del os.environ["PMV_PIPE_DEPTH"]
     ok = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=n, max_tracks=4096)      # and the library is still usable afterwards
     ok.frames_stage(0, frames)
     assert len(ok.pipeline_run(n, cfg["w"], cfg["h"], K, poses, threaded=1).poses) > 10
