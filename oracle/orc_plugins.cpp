@@ -143,6 +143,7 @@ int orc_pipeline_num_poses(void* h) { return vo::pipeline_num_poses(*(vo::Pipeli
 void orc_pipeline_get_poses(void* h, double* out) { vo::pipeline_get_poses(*(vo::PipelineRun*)h, out); }
 int orc_pipeline_num_frames(void* h) { return vo::pipeline_num_frames(*(vo::PipelineRun*)h); }
 int orc_pipeline_frame_feature_count(void* h, int k) { return vo::pipeline_frame_feature_count(*(vo::PipelineRun*)h, k); }
+int orc_pipeline_frame_corr_count(void* h, int k) { return vo::pipeline_frame_corr_count(*(vo::PipelineRun*)h, k); }
 void orc_pipeline_get_frame_features(void* h, int k, int* out) { vo::pipeline_get_frame_features(*(vo::PipelineRun*)h, k, out); }
 int orc_pipeline_stats_count(void) { return vo::PIPELINE_STATS_COUNT; }
 void orc_pipeline_get_stats(void* h, double* out25) { vo::pipeline_get_stats(*(vo::PipelineRun*)h, out25); }

@@ -81,6 +81,7 @@ inline void pipeline_get_poses(const PipelineRun& run, double* out) {
 }
 inline int pipeline_num_frames(const PipelineRun& run) { return (int)run.pipe.frames.size(); }
 inline int pipeline_frame_feature_count(const PipelineRun& run, int k) { return (int)run.pipe.frames[k]->map.size(); }
+inline int pipeline_frame_corr_count(const PipelineRun& run, int k) { return (int)run.pipe.frames[k]->feat_corr.size(); }   // incl. quirk Q10's empty entries
 // (column, row, landmark id or -1) per map entry, in the container's iteration order
 inline void pipeline_get_frame_features(const PipelineRun& run, int k, int* out) {
     int i = 0;

@@ -119,8 +119,8 @@ def load():
     global _cached
     if _cached is None:
         so = os.path.join(ROOT, "oracle", "liborc.so")
-        if not os.path.exists(so) or os.environ.get("PMV_REBUILD_ORACLE"):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+        # make decides (liborc.so depends on oracle/*.cpp, *.h and the host/ sources it shares): a stale library must never be the checker
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
         _cached = Oracle(C.CDLL(so))
     return _cached
 
@@ -149,6 +149,7 @@ class PipelineResult:
             if c:
                 g("get_frame_features")(handle, k, _p(a, _i32p))
             self.features.append(a)
+        self.corr_counts = [getattr(lib, prefix + "frame_corr_count")(handle, k) for k in range(nf)] if hasattr(lib, prefix + "frame_corr_count") else None
         st = np.zeros(g("stats_count")(), np.float64)
         g("get_stats")(handle, _p(st, _f64p))
         keys = ["lk_calls", "lk_points", "detect_calls", "pnp_calls", "pnp_points", "tri_calls", "ba_calls", "ba_obs",
@@ -164,6 +165,7 @@ def run_pipeline(frames, K, gt_poses, min_tracked=400, tol=150, init_frames=5, b
     o = load()
     lib = lib or o.lib
     lib.orc_pipeline_run.restype = C.c_void_p
+    lib.orc_pipeline_frame_corr_count.argtypes = [C.c_void_p, C.c_int]
     for f in ("orc_pipeline_free", "orc_pipeline_num_poses", "orc_pipeline_get_poses", "orc_pipeline_num_frames",
               "orc_pipeline_frame_feature_count", "orc_pipeline_get_frame_features", "orc_pipeline_get_stats"):
         getattr(lib, f).argtypes = [C.c_void_p] + ([C.c_int] if "frame_f" in f or "get_frame" in f else [])
