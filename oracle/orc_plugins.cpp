@@ -8,6 +8,9 @@
 #include "orc_fast.h"
 #include "vo_capi_impl.h"
 #include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
 #include <cstdlib>
 #include <stdexcept>
 
@@ -169,25 +172,107 @@ double orc_host_yrot(const double* R9, int flip) { vo::Mat3 R; memcpy(R.m, R9, 7
 // insert n features (col,row) into a Frame::map in the given order; out = iteration order as indices into the input
 void orc_host_map_order(const int* cols, const int* rows, int n, int* out) {
     vo::Frame fr;
-    std::vector<std::shared_ptr<vo::Feature>> keep;
-    std::unordered_map<vo::Feature*, int> idx;
-    for (int i = 0; i < n; i++) {
-        auto f = std::make_shared<vo::Feature>(cols[i], rows[i]);
-        keep.push_back(f); idx[f.get()] = i;
-        fr.map[f] = std::weak_ptr<vo::Feature3D>();
-    }
+    for (int i = 0; i < n; i++) fr.add_feature(cols[i], rows[i], -1);
     int k = 0;
-    for (auto& p : fr.map) out[k++] = idx[p.first.get()];
+    fr.for_each_feature([&](int e) { out[k++] = e; });
+}
+// the same insertions into the reference's own container type (std::unordered_map<shared_ptr<Feature>, weak_ptr<Feature3D>,
+// Feature::Hasher>, pointer equality) written out here: what vo::HashOrder has to reproduce
+}  // extern "C"
+namespace {
+struct RefFeature { int row, column; };
+struct RefHasher {   // Feature.h:28-48
+    std::size_t operator()(const std::shared_ptr<RefFeature> f) const {
+        size_t const h1(std::hash<std::string>{}(std::to_string(f->column)));
+        size_t const h2(std::hash<std::string>{}(std::to_string(f->row)));
+        return h1 ^ (h2 << 1);
+    }
+};
+}
+extern "C" {
+void orc_host_map_order_stdlib(const int* cols, const int* rows, int n, int* out) {
+    std::unordered_map<std::shared_ptr<RefFeature>, int, RefHasher> m;
+    for (int i = 0; i < n; i++) m[std::make_shared<RefFeature>(RefFeature{rows[i], cols[i]})] = i;
+    int k = 0;
+    for (auto& p : m) out[k++] = p.second;
+}
+// vo::HashOrder against std::unordered_map on arbitrary hash codes (collisions, equal codes, growth through many bucket counts):
+// n keys with the given codes are inserted in order into both; returns the number of positions where the iteration orders differ
+// (0 = identical), and also checks find() for every key and for n absent codes
+}  // extern "C"
+namespace {
+struct CodeKey { size_t code; int id; bool operator==(const CodeKey& o) const { return id == o.id; } };
+struct CodeHash { size_t operator()(const CodeKey& k) const { return k.code; } };   // (not noexcept, like Feature::Hasher)
+}
+extern "C" {
+int orc_host_hashorder_check(const uint64_t* codes, int n) {
+    std::unordered_map<CodeKey, int, CodeHash> real;
+    vo::HashOrder emu;
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        real[CodeKey{(size_t)codes[i], i}] = i;
+        if (emu.insert((size_t)codes[i]) != i) bad++;
+        if (real.bucket_count() != emu.bucket_count()) bad++;
+        if ((i & (i + 1)) == 0 || i == n - 1) {   // compare the whole order at sizes 1, 2, 4, ... and at the end
+            int p = emu.head();
+            for (auto& kv : real) { if (p != kv.second) bad++; p = p >= 0 ? emu.next(p) : -1; }
+            if (p != -1) bad++;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        if (emu.find((size_t)codes[i], [&](int node) { return node == i; }) != i) bad++;
+        if (emu.find((size_t)codes[i] + 0x9e3779b97f4a7c15ull, [&](int) { return true; }) != -1 && real.find(CodeKey{(size_t)codes[i] + 0x9e3779b97f4a7c15ull, -1}) == real.end()) {
+            // an absent code may still share a bucket with present nodes; a hit needs an equal code, which the predicate-less probe accepts
+            bool exists = false;
+            for (int j = 0; j < n; j++) if ((size_t)codes[j] == (size_t)codes[i] + 0x9e3779b97f4a7c15ull) exists = true;
+            if (!exists) bad++;
+        }
+    }
+    return bad;
 }
 // feat_corr semantics: keys compare by coordinates (same-pixel sources collapse, last value wins). Returns the number of
 // entries; out_key / out_val = indices of the surviving key feature and of its value, in iteration order
 int orc_host_corr_order(const int* cols, const int* rows, int n, int* out_key, int* out_val) {
+    vo::Frame src, next;
     vo::fmap corr;
-    std::vector<std::shared_ptr<vo::Feature>> src, dst;
-    std::unordered_map<vo::Feature*, int> si, di;
     for (int i = 0; i < n; i++) {
-        auto a = std::make_shared<vo::Feature>(cols[i], rows[i]);
-        auto b = std::make_shared<vo::Feature>(cols[i] + 1000, rows[i] + 1000);
+        const int a = src.add_feature(cols[i], rows[i], -1);
+        const int b = next.add_feature(cols[i] + 1000, rows[i] + 1000, -1);
+        corr.val[(size_t)src.corr_at(corr, a)] = b;   // corr[a] = b
+    }
+    int k = 0;
+    corr.order.for_each([&](int c) { out_key[k] = corr.key[(size_t)c]; out_val[k] = corr.val[(size_t)c]; k++; });
+    return k;
+}
+// the same through the reference's own container type: unordered_map<weak_ptr<Feature>, weak_ptr<Feature>, Hasher> with the
+// coordinate operator== of Feature.cpp:48-55
+}  // extern "C"
+namespace refcorr {
+struct Feature { int row, column; };
+struct Hasher {
+    std::size_t operator()(const std::weak_ptr<Feature> f) const {
+        if (f.expired()) return 0;
+        std::shared_ptr<Feature> p = f.lock();
+        size_t const h1(std::hash<std::string>{}(std::to_string(p->column)));
+        size_t const h2(std::hash<std::string>{}(std::to_string(p->row)));
+        return h1 ^ (h2 << 1);
+    }
+};
+bool operator==(const std::weak_ptr<Feature> lhs, const std::weak_ptr<Feature> rhs) {
+    if (lhs.expired() || rhs.expired()) return false;
+    std::shared_ptr<Feature> a = lhs.lock(), b = rhs.lock();
+    return a->column == b->column && a->row == b->row;
+}
+}
+extern "C" {
+int orc_host_corr_order_stdlib(const int* cols, const int* rows, int n, int* out_key, int* out_val) {
+    typedef refcorr::Feature RF;
+    std::unordered_map<std::weak_ptr<RF>, std::weak_ptr<RF>, refcorr::Hasher> corr;
+    std::vector<std::shared_ptr<RF>> src, dst;
+    std::unordered_map<RF*, int> si, di;
+    for (int i = 0; i < n; i++) {
+        auto a = std::make_shared<RF>(RF{rows[i], cols[i]});
+        auto b = std::make_shared<RF>(RF{rows[i] + 1000, cols[i] + 1000});
         src.push_back(a); dst.push_back(b); si[a.get()] = i; di[b.get()] = i;
         corr[a] = b;
     }
@@ -216,13 +301,11 @@ void orc_host_ba_schedule(int bundle_size, int n_frames, int* out_trig, int* out
     pl.cfg.tracked_features_tol = 0;   // count3DPoints() >= 0: always the PnP branch
     NullPnP pnp; RecordingBA ba; ba.tracker = &pl;
     pl.pnpsolver = &pnp; pl.ba = &ba;
-    auto lm = std::make_shared<vo::Feature3D>(1.0, 2.0, -9.0);
-    lm->id = 0;
-    pl.feats3d.push_back(lm);
+    const int lm = pl.landmarks.create(vo::Feature3D(1.0, 2.0, -9.0));
     for (int i = 0; i < n_frames; i++) {
         auto fr = std::make_shared<vo::Frame>();
         fr->frame = i;
-        fr->map[std::make_shared<vo::Feature>(10 + i, 20)] = lm;
+        fr->add_feature(10 + i, 20, lm);
         pl.frames.push_back(fr);
     }
     pl.scale = 1.0;
@@ -263,14 +346,14 @@ int orc_host_motion_heuristics(int n, const double* R, const double* t, const do
 // neighbour. out[i] = grid answer | (scan answer << 1).
 void orc_host_neighbor_grid(const int* map_xy, int n_map, const int* cand_xy, const int* add_xy, int n_cand, int* out) {
     vo::Frame fr;
-    for (int i = 0; i < n_map; i++) fr.map[std::make_shared<vo::Feature>(map_xy[2 * i], map_xy[2 * i + 1])] = std::weak_ptr<vo::Feature3D>();
+    for (int i = 0; i < n_map; i++) fr.add_feature(map_xy[2 * i], map_xy[2 * i + 1], -1);
     vo::NeighborGrid grid(fr);
     for (int i = 0; i < n_cand; i++) {
         vo::Feature f(cand_xy[2 * i], cand_xy[2 * i + 1]);
         const bool a = grid.hasNeighbor(f.column, f.row), b = fr.hasNeighbor(f);
         out[i] = (a ? 1 : 0) | (b ? 2 : 0);
         if (!b) {
-            fr.map[std::make_shared<vo::Feature>(add_xy[2 * i], add_xy[2 * i + 1])] = std::weak_ptr<vo::Feature3D>();
+            fr.add_feature(add_xy[2 * i], add_xy[2 * i + 1], -1);
             grid.add(add_xy[2 * i], add_xy[2 * i + 1]);
         }
     }

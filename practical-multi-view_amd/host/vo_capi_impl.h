@@ -80,16 +80,18 @@ inline void pipeline_get_poses(const PipelineRun& run, double* out) {
     }
 }
 inline int pipeline_num_frames(const PipelineRun& run) { return (int)run.pipe.frames.size(); }
-inline int pipeline_frame_feature_count(const PipelineRun& run, int k) { return (int)run.pipe.frames[k]->map.size(); }
+inline int pipeline_frame_feature_count(const PipelineRun& run, int k) { return run.pipe.frames[k]->n_features(); }
 inline int pipeline_frame_corr_count(const PipelineRun& run, int k) { return (int)run.pipe.frames[k]->feat_corr.size(); }   // incl. quirk Q10's empty entries
 // (column, row, landmark id or -1) per map entry, in the container's iteration order
 inline void pipeline_get_frame_features(const PipelineRun& run, int k, int* out) {
+    const Frame& fr = *run.pipe.frames[k];
+    const LandmarkTable& L = run.pipe.landmarks;
     int i = 0;
-    for (auto& p : run.pipe.frames[k]->map) {
-        out[3 * i] = p.first->column; out[3 * i + 1] = p.first->row;
-        out[3 * i + 2] = p.second.expired() ? -1 : p.second.lock()->id;
+    fr.for_each_feature([&](int e) {
+        out[3 * i] = fr.column[(size_t)e]; out[3 * i + 1] = fr.row[(size_t)e];
+        out[3 * i + 2] = L.expired(fr.lm[(size_t)e]) ? -1 : fr.lm[(size_t)e];
         i++;
-    }
+    });
 }
 // PIPELINE_STATS_COUNT doubles: counters, run seconds, and per-stage wall seconds of the calling host threads (the field list is
 // documented at pmv_pipeline_get_stats in include/pmv_hip.h)
@@ -98,7 +100,7 @@ inline void pipeline_get_stats(const PipelineRun& run, double* out25) {
     const Stats& s = run.pipe.stats;
     const double v[PIPELINE_STATS_COUNT] = {(double)s.lk_calls, (double)s.lk_points, (double)s.detect_calls, (double)s.pnp_calls, (double)s.pnp_points,
                           (double)s.tri_calls, (double)s.ba_calls, (double)s.ba_obs, (double)s.ba_points, (double)s.heuristic_motion,
-                          run.seconds, (double)run.pipe.init_offset, (double)run.pipe.feats3d.size(), run.pipe.scale,
+                          run.seconds, (double)run.pipe.init_offset, (double)run.pipe.landmarks.n_alive, run.pipe.scale,
                           s.t_lk, s.t_detect, s.t_pnp, s.t_tri, s.t_ba, s.t_pnp_kernel, s.t_ba_kernel, s.t_tri_essential, s.t_tri_pose, s.tri_hypotheses, (double)s.tri_ahead};
     memcpy(out25, v, sizeof(v));
 }

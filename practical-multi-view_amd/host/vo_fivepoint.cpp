@@ -574,18 +574,18 @@ void dlt_candidates_host(const double* q1, const double* q2, int n, const double
 }
 
 // ---- findEssentialMat ahead of time (see vo_pipeline.h) ----------------------------------------------------------------
-void FivePointTri::prefetch(const Frame& prev) {
+void FivePointTri::prefetch(const Frame& prev, const Frame& next) {
     if (prefetch_threads <= 0 || use_hypothesis_hook) return;
     auto job = std::make_shared<EssentialJob>();
     job->frame = prev.frame;
-    job->p1.reserve(2 * prev.feat_corr.size()); job->p2.reserve(2 * prev.feat_corr.size());
-    for (auto& p : prev.feat_corr) {   // the loop of triangulate() (OpenCVFivePointTri.cpp:9-22), coordinates only
-        if (p.first.expired() || p.second.expired()) continue;
-        std::shared_ptr<Feature> fst = p.first.lock();
-        std::shared_ptr<Feature> sec = p.second.lock();
-        job->p1.push_back(fst->column); job->p1.push_back(fst->row);
-        job->p2.push_back(sec->column); job->p2.push_back(sec->row);
-    }
+    const FeatureCorr& fc = prev.feat_corr;
+    job->p1.reserve(2 * fc.size()); job->p2.reserve(2 * fc.size());
+    fc.order.for_each([&](int c) {   // the loop of triangulate() (OpenCVFivePointTri.cpp:9-22), coordinates only
+        const int fst = fc.key[(size_t)c], sec = fc.val[(size_t)c];
+        if (sec < 0) return;
+        job->p1.push_back(prev.column[(size_t)fst]); job->p1.push_back(prev.row[(size_t)fst]);
+        job->p2.push_back(next.column[(size_t)sec]); job->p2.push_back(next.row[(size_t)sec]);
+    });
     std::lock_guard<std::mutex> lk(pf_mu);
     if (pf_threads.empty())
         for (int i = 0; i < prefetch_threads; i++) pf_threads.emplace_back([this] { prefetch_worker(); });
@@ -629,7 +629,7 @@ FivePointTri::~FivePointTri() { finish(); }
 void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
     const int j = src.frame;
     std::vector<double> p1, p2;
-    std::vector<std::shared_ptr<Feature>> p1_ptr, p2_ptr;
+    std::vector<int> p1_ptr, p2_ptr;   // the two features of each correspondence: rows of src / next
     // a result (or a job) from the front-end's prefetch for this frame pair; older entries belong to frames that went through PnP
     std::shared_ptr<EssentialJob> job;
     if (prefetch_threads > 0) {
@@ -646,26 +646,17 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
         pool->begin();
     }
     HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[4]);
-    // the front-end's list of this pair (TriLink): the same correspondences in the same order, with the map nodes that receive the landmarks
-    const bool flat = src.tri_links_src == (const void*)&src.map && src.pnp_links_for == (const void*)&next.map;
-    if (flat) {
-        p1.reserve(2 * src.tri_links.size()); p2.reserve(2 * src.tri_links.size());
-        for (const TriLink& T : src.tri_links) {
-            p1.push_back(T.fst->column); p1.push_back(T.fst->row);     // integer cv::Point (quirk Q12)
-            p2.push_back(T.sec->column); p2.push_back(T.sec->row);
-        }
-    } else {
-        for (auto& p : src.map) { p.first->map_slot = &p.second; p.first->map_owner = &src.map; }     // src.map[..] / next.map[..] below without hashing
-        for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }
-        for (auto& p : src.feat_corr) {
-            if (p.first.expired() || p.second.expired()) continue;
-            std::shared_ptr<Feature> fst = p.first.lock();
-            std::shared_ptr<Feature> sec = p.second.lock();
-            p1.push_back(fst->column); p1.push_back(fst->row);     // integer cv::Point (quirk Q12)
-            p2.push_back(sec->column); p2.push_back(sec->row);
+    {
+        const FeatureCorr& fc = src.feat_corr;
+        p1.reserve(2 * fc.size()); p2.reserve(2 * fc.size()); p1_ptr.reserve(fc.size()); p2_ptr.reserve(fc.size());
+        fc.order.for_each([&](int c) {   // for (auto& p : src.feat_corr)
+            const int fst = fc.key[(size_t)c], sec = fc.val[(size_t)c];
+            if (sec < 0) return;                                                     // p.second.expired(): the empty entries of quirk Q10
+            p1.push_back(src.column[(size_t)fst]); p1.push_back(src.row[(size_t)fst]);     // integer cv::Point (quirk Q12)
+            p2.push_back(next.column[(size_t)sec]); p2.push_back(next.row[(size_t)sec]);
             p1_ptr.push_back(fst);
             p2_ptr.push_back(sec);
-        }
+        });
     }
     delete hpg;
     const int n = (int)(p1.size() / 2);
@@ -716,20 +707,12 @@ void FivePointTri::triangulate(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out
     for (int i = 0; i < n; i++) {
         if (!mask[i]) continue;   // Removing RANSAC outliers
         const double w = tri[(size_t)3 * n + i];
-        std::shared_ptr<Feature3D> f3d = std::make_shared<Feature3D>(tracker->scale * tri[i] / w, tracker->scale * tri[(size_t)n + i] / w,
-                                                                      tracker->scale * tri[(size_t)2 * n + i] / w * -1);
-        if (f3d->z < 0) {
-            f3d->id = tracker->next_landmark_id++;
-            f3d->transform(tracker->R[j], tracker->t[j]);
-            tracker->feats3d.push_back(f3d);
-            f3d->self = std::prev(tracker->feats3d.end());
-            if (flat) {
-                *src.tri_links[i].next_slot = std::weak_ptr<Feature3D>(f3d);
-                *src.tri_links[i].src_slot = std::weak_ptr<Feature3D>(f3d);
-            } else {
-                if (p2_ptr[i]->map_owner == (const void*)&next.map) *p2_ptr[i]->map_slot = std::weak_ptr<Feature3D>(f3d); else next.map[p2_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
-                if (p1_ptr[i]->map_owner == (const void*)&src.map) *p1_ptr[i]->map_slot = std::weak_ptr<Feature3D>(f3d); else src.map[p1_ptr[i]] = std::weak_ptr<Feature3D>(f3d);
-            }
+        Feature3D f3d(tracker->scale * tri[i] / w, tracker->scale * tri[(size_t)n + i] / w, tracker->scale * tri[(size_t)2 * n + i] / w * -1);
+        if (f3d.z < 0) {
+            f3d.transform(tracker->R[j], tracker->t[j]);
+            const int id = tracker->landmarks.create(f3d);   // tracker->feats3d.push_back(f3d_ptr)
+            next.lm[(size_t)p2_ptr[(size_t)i]] = id;         // next.map[p2_ptr[i]] = weak_ptr(f3d_ptr)
+            src.lm[(size_t)p1_ptr[(size_t)i]] = id;          // src.map[p1_ptr[i]] = weak_ptr(f3d_ptr)
         }
     }
 }

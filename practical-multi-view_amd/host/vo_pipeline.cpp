@@ -24,6 +24,72 @@ size_t coord_hash(int v) {
     return std::hash<std::string>{}(std::to_string(v));
 }
 
+// ---- HashOrder: libstdc++'s _Hashtable (unique keys), replayed over node indices ----------------------------------------------
+// Bucket counts of _Prime_rehash_policy as a function of the element count, read off the real container once (so the prime table
+// and the growth rule are libstdc++'s own, whatever version this is built with).
+size_t HashOrder::buckets_for(size_t n) {
+    static const std::vector<unsigned>* table = [] {
+        constexpr size_t N = 1u << 17;
+        auto* t = new std::vector<unsigned>(N + 1);
+        std::unordered_map<int, int> m;
+        (*t)[0] = (unsigned)m.bucket_count();
+        for (size_t i = 1; i <= N; i++) { m.emplace((int)i, 0); (*t)[i] = (unsigned)m.bucket_count(); }
+        return t;
+    }();
+    if (n < table->size()) return (*table)[n];
+    std::unordered_map<int, int> m;   // (beyond the table: ask the container itself)
+    for (size_t i = 1; i <= n; i++) m.emplace((int)i, 0);
+    return m.bucket_count();
+}
+// _M_rehash_aux(n, true_type): the nodes are re-linked in their current order; a node whose new bucket is still empty goes to the
+// FRONT of the list, otherwise behind the first node ("before" node) of its bucket
+void HashOrder::rehash(size_t n) {
+    std::vector<int> nb(n, EMPTY);
+    int p = head_;
+    head_ = -1;
+    size_t bbegin_bkt = 0;
+    while (p >= 0) {
+        const int nx = next_[(size_t)p];
+        const size_t bkt = code_[(size_t)p] % n;
+        if (nb[bkt] == EMPTY) {
+            next_[(size_t)p] = head_;
+            head_ = p;
+            nb[bkt] = BEFORE_BEGIN;
+            if (next_[(size_t)p] >= 0) nb[bbegin_bkt] = p;
+            bbegin_bkt = bkt;
+        } else if (nb[bkt] == BEFORE_BEGIN) {
+            next_[(size_t)p] = head_;
+            head_ = p;
+        } else {
+            const int prev = nb[bkt];
+            next_[(size_t)p] = next_[(size_t)prev];
+            next_[(size_t)prev] = p;
+        }
+        p = nx;
+    }
+    bprev_.swap(nb);
+    nb_ = n;
+}
+// _M_insert_unique_node: grow first (by the policy's count for one more element), then _M_insert_bucket_begin
+int HashOrder::insert(size_t code) {
+    const int node = (int)next_.size();
+    const size_t want = buckets_for((size_t)node + 1);
+    if (want != nb_ || bprev_.empty()) rehash(want);
+    const size_t bkt = code % nb_;
+    next_.push_back(-1);
+    code_.push_back(code);
+    const int prev = bprev_[bkt];
+    if (prev == BEFORE_BEGIN) { next_[(size_t)node] = head_; head_ = node; }
+    else if (prev != EMPTY) { next_[(size_t)node] = next_[(size_t)prev]; next_[(size_t)prev] = node; }
+    else {
+        next_[(size_t)node] = head_;
+        head_ = node;
+        if (next_[(size_t)node] >= 0) bprev_[code_[(size_t)next_[(size_t)node]] % nb_] = node;
+        bprev_[bkt] = BEFORE_BEGIN;
+    }
+    return node;
+}
+
 void rodrigues_v2m(const double r[3], double R[9]) { vmath::rodrigues_v2m(r, R); }
 void rodrigues_m2v(const double R[9], double r[3]) { vmath::rodrigues_m2v(R, r); }
 
@@ -109,35 +175,34 @@ std::vector<std::vector<Feature>> FastExtractorBase::extractGrid(std::vector<Fra
 fmap KnnFeatureMatcherBase::matchFeatures(Frame& src, Frame& next) {
     fmap map;
     double avg = 0;
-    std::vector<std::shared_ptr<Feature>> new_feats, old_feats;
-    std::vector<bool> tracked;
+    std::vector<Feature> new_feats;
+    std::vector<int> old_feats;   // features of src in the order src.map is walked
     std::vector<Feature> cmp_feats = extractor->extractFeatures(next, 1000);   // :11, on the whole next frame
-    for (auto& p : src.map) old_feats.push_back(p.first);
+    src.for_each_feature([&](int e) { old_feats.push_back(e); });
     const int n = (int)old_feats.size(), m = (int)cmp_feats.size();
     std::vector<int> src_xy(2 * (size_t)n), cmp_xy(2 * (size_t)m), best(n, -1);
     std::vector<float> errs(n, 0.f);
-    for (int i = 0; i < n; i++) { src_xy[2 * i] = old_feats[i]->column; src_xy[2 * i + 1] = old_feats[i]->row; }
+    for (int i = 0; i < n; i++) { src_xy[2 * i] = src.column[(size_t)old_feats[i]]; src_xy[2 * i + 1] = src.row[(size_t)old_feats[i]]; }
     for (int j = 0; j < m; j++) { cmp_xy[2 * j] = cmp_feats[j].column; cmp_xy[2 * j + 1] = cmp_feats[j].row; }
     if (n > 0) knn(src.bw, next.bw, src_xy.data(), n, cmp_xy.data(), m, best.data(), errs.data());   // :15-31 for every feature
     for (int i = 0; i < n; i++) {
         Feature best_fit = best[i] >= 0 ? cmp_feats[best[i]] : Feature();   // the neighbour copy (default-constructed when there was none)
         const float err = errs[i];
         if (err < threshold) {
-            tracked.push_back(true);
             best_fit.tracked = true;
-            best_fit.displacement = old_feats[i]->distance(best_fit);
+            best_fit.displacement = Feature(src_xy[2 * i], src_xy[2 * i + 1]).distance(best_fit);
             avg += best_fit.displacement;
-        } else
-            tracked.push_back(false);   // (the copy keeps the candidate's own `tracked` flag: quirk of the reference, :32-41)
-        new_feats.push_back(std::make_shared<Feature>(best_fit));
+        }   // (else: the copy keeps the candidate's own `tracked` flag: quirk of the reference, :32-41)
+        new_feats.push_back(best_fit);
     }
     avg /= (double)new_feats.size();
     for (auto& f : new_feats)
-        if (f->displacement > 3 * avg) f->tracked = false;
+        if (f.displacement > 3 * avg) f.tracked = false;
     for (size_t i = 0; i < old_feats.size(); i++)
-        if (new_feats[i]->tracked) {
-            next.map[new_feats[i]] = src.map[old_feats[i]];
-            map[old_feats[i]] = new_feats[i];
+        if (new_feats[i].tracked) {
+            const int e_new = next.add_feature(new_feats[i].column, new_feats[i].row, src.lm[(size_t)old_feats[i]]);   // next.map[new] = src.map[old]
+            const int c = src.corr_at(map, old_feats[i]);                                                            // map[old] = new
+            map.val[(size_t)c] = e_new;
         }
     return map;
 }
@@ -145,131 +210,63 @@ fmap KnnFeatureMatcherBase::matchFeatures(Frame& src, Frame& next) {
 // ---- OpenCVLucasKanadeFM.cpp:5-32 ----------------------------------------------------------------------------
 fmap LucasKanadeFMBase::matchFeatures(Frame& src, Frame& next) {
     fmap correspondences;
-    std::vector<float> prev_points, next_points;
-    for (auto const& p : src.map) {
-        prev_points.push_back((float)p.first->column);
-        prev_points.push_back((float)p.first->row);
+    const int n = src.n_features();
+    std::vector<int> walk((size_t)n);           // src.map in iteration order
+    std::vector<float> prev_points(2 * (size_t)n), next_points(2 * (size_t)n);
+    {
+        int i = 0;
+        src.for_each_feature([&](int e) {
+            walk[(size_t)i] = e;
+            prev_points[2 * (size_t)i] = (float)src.column[(size_t)e];
+            prev_points[2 * (size_t)i + 1] = (float)src.row[(size_t)e];
+            i++;
+        });
     }
-    const int n = (int)(prev_points.size() / 2);
-    next_points.resize(prev_points.size());
-    std::vector<uint8_t> status(n);
-    std::vector<float> err(n);
+    std::vector<uint8_t> status((size_t)n);
+    std::vector<float> err((size_t)n);
     if (n > 0) pyrlk(src.bw, next.bw, prev_points.data(), n, next_points.data(), status.data(), err.data());
-    int i = 0;
-    for (auto const& p : src.map) {
-        if ((int)status.size() < i + 1) continue;
-        if (status[i]) {
-            // Feature(next_points[i].x, next_points[i].y): float -> int truncation toward zero
-            std::shared_ptr<Feature> f = std::make_shared<Feature>(Feature((int)next_points[2 * i], (int)next_points[2 * i + 1]));
-            next.map[f] = p.second;
-            correspondences[p.first] = f;
-        }
-        i++;
+    next.column.reserve((size_t)n + 512); next.row.reserve((size_t)n + 512); next.lm.reserve((size_t)n + 512); next.map_order.reserve_nodes((size_t)n + 512);
+    correspondences.key.reserve((size_t)n); correspondences.val.reserve((size_t)n); correspondences.order.reserve_nodes((size_t)n);
+    for (int i = 0; i < n; i++) {
+        if (!status[(size_t)i]) continue;
+        const int e = walk[(size_t)i];
+        // Feature(next_points[i].x, next_points[i].y): float -> int truncation toward zero
+        const int f = next.add_feature((int)next_points[2 * (size_t)i], (int)next_points[2 * (size_t)i + 1], src.lm[(size_t)e]);   // next.map[f] = p.second
+        const int c = src.corr_at(correspondences, e);   // correspondences[p.first] = f (same-pixel sources share the entry; the last value wins)
+        correspondences.val[(size_t)c] = f;
     }
     return correspondences;
 }
 
 // ---- OpenCVEPnPSolver.cpp:4-50 ---------------------------------------------------------------------------------
-// front-end: remember, in the key object of every feat_corr entry, where the entry lives (see Feature::corr_slot)
-static void index_feat_corr(Frame& fr) {
-    for (auto& p : fr.feat_corr)
-        if (std::shared_ptr<Feature> k = p.first.lock()) { k->corr_slot = &p.second; k->corr_owner = &fr.feat_corr; k->corr_feat = p.second.lock().get(); }
-}
-
-// front-end: the gather list of solvePnP(src, next) (see PnPLink). `next` must be at its final address with all its features in.
-static void build_pnp_links(Frame& src, Frame& next) {
-    for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }
-    src.pnp_links.clear();
-    src.pnp_links.reserve(src.map.size());
-    for (auto& p : src.map) {
-        PnPLink L;
-        L.src_val = &p.second; L.key = &p.first;
-        L.key_column = p.first->column; L.key_row = p.first->row;
-        if (p.first->corr_owner == (const void*)&src.feat_corr) {   // this very object is the key of its feat_corr entry
-            Feature* f = p.first->corr_feat;
-            if (!f) L.kind = 0;
-            else if (f->map_owner == (const void*)&next.map) { L.kind = 1; L.next_slot = f->map_slot; L.f = f; }
-            else {   // not a key object of next.map: an equal key's node is where next.map[f] lands; no such node -> operator[] would insert
-                std::shared_ptr<Feature> fs = p.first->corr_slot->lock();
-                auto it = fs ? next.map.find(fs) : next.map.end();
-                if (it != next.map.end()) { L.kind = 1; L.next_slot = &it->second; L.f = f; }
-            }
-        }
-        src.pnp_links.push_back(L);
-    }
-    src.pnp_links_for = &next.map;
-    // the two-view gather (OpenCVFivePointTri.cpp:9-22) and where its landmarks go (:47-50)
-    for (auto& p : src.map) { p.first->map_slot = &p.second; p.first->map_owner = &src.map; }   // (src's hints pointed into the map of its own build step)
-    src.tri_links.clear();
-    src.tri_links.reserve(src.feat_corr.size());
-    bool complete = true;
-    for (auto& p : src.feat_corr) {
-        if (p.first.expired() || p.second.expired()) continue;
-        std::shared_ptr<Feature> fst = p.first.lock(), sec = p.second.lock();
-        TriLink T;
-        T.fst = fst.get(); T.sec = sec.get();
-        if (fst->map_owner == (const void*)&src.map) T.src_slot = fst->map_slot;
-        else { auto it = src.map.find(fst); if (it != src.map.end()) T.src_slot = &it->second; }
-        if (sec->map_owner == (const void*)&next.map) T.next_slot = sec->map_slot;
-        else { auto it = next.map.find(sec); if (it != next.map.end()) T.next_slot = &it->second; }
-        if (!T.src_slot || !T.next_slot) complete = false;   // operator[] would insert a node: leave this pair to the reference's loop
-        src.tri_links.push_back(T);
-    }
-    src.tri_links_src = complete ? (const void*)&src.map : nullptr;
-}
-
 void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out) {
     const int j = src.frame;
     std::vector<float> obj_points, img_points;
     double _R_rod[3];
     rodrigues_m2v(R_out.m, _R_rod);
-    std::vector<std::weak_ptr<Feature3D>> local_feats3d;
+    std::vector<int> local_feats3d;
+    LandmarkTable& L = tracker->landmarks;
     HostProfScope* hps = new HostProfScope(tracker->stats.hp.t[0]);
-    obj_points.reserve(3 * src.map.size()); img_points.reserve(2 * src.map.size()); local_feats3d.reserve(src.map.size());
-    const auto take = [&](std::shared_ptr<Feature3D>& f3d, const Feature* f) {   // :22-27 for one landmark / image point pair
-        f3d->transformInv(tracker->R[j], tracker->t[j]);
-        float px = f3d->x, py = f3d->y, pz = f3d->z;
+    obj_points.reserve(3 * (size_t)src.n_features()); img_points.reserve(2 * (size_t)src.n_features()); local_feats3d.reserve((size_t)src.n_features());
+    const Mat3& Rj = tracker->R[j];
+    const Vec3& tj = tracker->t[j];
+    src.for_each_feature([&](int e) {   // for (auto& p : src.map)
+        const int id = src.lm[(size_t)e];
+        if (L.expired(id)) return;
+        const int c = src.corr_at(src.feat_corr, e);   // src.feat_corr[p.first]: operator[] inserts an empty entry when there is none (quirk Q10)
+        const int f = src.feat_corr.val[(size_t)c];
+        if (f < 0) return;                             // .expired()
+        next.lm[(size_t)f] = id;                       // next.map[f] = weak_ptr(f3d)
+        Feature3D f3d = L.get(id);
+        f3d.transformInv(Rj, tj);
+        float px = f3d.x, py = f3d.y, pz = f3d.z;
         pz *= -1;
         obj_points.push_back(px); obj_points.push_back(py); obj_points.push_back(pz);
-        img_points.push_back((float)f->column); img_points.push_back((float)f->row);
-        f3d->transform(tracker->R[j], tracker->t[j]);       // float round trip (quirk Q7)
-        local_feats3d.push_back(std::move(f3d));
-    };
-    // one src.map entry the way the reference walks it. src.feat_corr[p.first]: the entry found by coordinate equality. If this very
-    // object is the entry's key the front-end left its address in corr_slot; otherwise (same-pixel twin, or no correspondence) look it
-    // up as the reference does - operator[] then inserts the empty entry of quirk Q10.
-    const auto slow_entry = [&](const std::shared_ptr<Feature>& key, std::shared_ptr<Feature3D>& f3d) {
-        Feature* f;
-        if (key->corr_owner == (const void*)&src.feat_corr) {
-            f = key->corr_feat;                       // no reference-count traffic on the (front-end-created) feature
-            if (!f) return;
-            if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
-            else next.map[key->corr_slot->lock()] = std::weak_ptr<Feature3D>(f3d);
-        } else {
-            std::shared_ptr<Feature> fs = src.feat_corr[key].lock();
-            if (!fs) return;
-            f = fs.get();
-            if (f->map_owner == (const void*)&next.map) *f->map_slot = std::weak_ptr<Feature3D>(f3d);
-            else next.map[fs] = std::weak_ptr<Feature3D>(f3d);
-        }
-        take(f3d, f);
-    };
-    if (src.pnp_links_for == (const void*)&next.map && src.pnp_links.size() == src.map.size()) {
-        // the front-end's list: same entries in the same order, only the landmark's liveness is looked up here
-        for (const PnPLink& L : src.pnp_links) {
-            std::shared_ptr<Feature3D> f3d = L.src_val->lock();    // (expired() + lock() in the reference: one atomic round trip here)
-            if (!f3d) continue;
-            if (L.kind == 1) { *L.next_slot = std::weak_ptr<Feature3D>(f3d); take(f3d, L.f); }
-            else if (L.kind == 2) slow_entry(*L.key, f3d);
-        }
-    } else {
-        for (auto& p : next.map) { p.first->map_slot = &p.second; p.first->map_owner = &next.map; }   // next.map[f] below without hashing
-        for (auto& p : src.map) {
-            std::shared_ptr<Feature3D> f3d = p.second.lock();
-            if (!f3d) continue;
-            slow_entry(p.first, f3d);
-        }
-    }
+        img_points.push_back((float)next.column[(size_t)f]); img_points.push_back((float)next.row[(size_t)f]);
+        f3d.transform(Rj, tj);                         // float round trip in place (quirk Q7)
+        L.put(id, f3d);
+        local_feats3d.push_back(id);
+    });
     delete hps;
     std::vector<int> inliers;
     const int m = (int)(obj_points.size() / 3);
@@ -282,41 +279,36 @@ void EPnPSolverBase::solvePnP(Frame& src, Frame& next, Mat3& R_out, Vec3& t_out)
     rodrigues_v2m(_R_rod, R_out.m);
     HostProfScope hps2(tracker->stats.hp.t[1]);
     // Removing RANSAC outliers (:40-49)
-    std::vector<uint8_t> is_inlier(m, 0);
-    for (int i : inliers) if (i >= 0 && i < m) is_inlier[i] = 1;
-    for (int i = 0; i < m; i++) {
-        if (!is_inlier[i]) {
-            if (local_feats3d[i].expired()) continue;
-            std::shared_ptr<Feature3D> f3d = local_feats3d[i].lock();
-            tracker->feats3d.erase(f3d->self);
-        }
-    }
+    std::vector<uint8_t> is_inlier((size_t)m, 0);
+    for (int i : inliers) if (i >= 0 && i < m) is_inlier[(size_t)i] = 1;
+    for (int i = 0; i < m; i++)
+        if (!is_inlier[(size_t)i] && !L.expired(local_feats3d[(size_t)i])) L.erase(local_feats3d[(size_t)i]);
 }
 
 // ---- CeresBundleAdjustment.cpp:5-89 ------------------------------------------------------------------------------
 void BundleAdjustmentBase::apply(Frame& f) {
     const int fn = (int)f.frame + 1;
     const int n = std::min(tracker->cfg.bundle_size, fn);
-    // Work vectors: local, sized from the previous solve so that they do not regrow element by element. (Keeping the buffers themselves
-    // between calls was measured and dropped: 6 ms per step for one sequence, but -7 % in the batched leg - 128 sequences x 50 KB of
-    // buffers that are touched every other frame instead of memory the allocator hands straight back to the next gather.)
+    LandmarkTable& L = tracker->landmarks;
+    // Work vectors: local, sized from the previous solve so that they do not regrow element by element.
     std::vector<int> cam_frame, obs_cam, obs_pt;      // window frames in order (skipping 0); camera / point index per residual block
     std::vector<double> tr_opt, obs;                  // 6 per window frame; 2 per residual block
     cam_frame.reserve((size_t)n); tr_opt.reserve((size_t)6 * n);
     obs.reserve(2 * last_obs + 64); obs_cam.reserve(last_obs + 32); obs_pt.reserve(last_obs + 32);
-    const unsigned epoch = ++epoch_counter;   // p3d_index of the reference, as epoch-stamped arrays over the landmark ids
-    std::vector<Feature3D*> p3d_ptr;                  // (raw: nothing erases a landmark between the gather and the update below; one thread)
+    const unsigned epoch = ++epoch_counter;   // p3d_opt.count(f3d) of the reference, as epoch-stamped arrays over the landmark ids
+    std::vector<int> p3d_id;
     std::vector<double> p3d_opt;
-    p3d_ptr.reserve(last_points + 32); p3d_opt.reserve(3 * last_points + 96);
+    p3d_id.reserve(last_points + 32); p3d_opt.reserve(3 * last_points + 96);
     HostProfScope* hpg = new HostProfScope(tracker->stats.hp.t[2]);
     std::vector<std::shared_ptr<Frame>> window((size_t)n);   // snapshot under the lock: the front-end thread may be appending
     {
         std::lock_guard<std::mutex> lk(tracker->frames_mu);
         for (int i = fn - n; i < fn; i++) window[(size_t)(i - (fn - n))] = tracker->frames[i];
     }
+    if (seen_epoch.size() < (size_t)L.size()) { seen_epoch.resize((size_t)L.size() + 4096, 0); seen_index.resize((size_t)L.size() + 4096, 0); }
     for (int i = fn - n; i < fn; i++) {
         if (i == 0) continue;
-        const std::shared_ptr<Frame>& frame = window[(size_t)(i - (fn - n))];
+        const Frame& frame = *window[(size_t)(i - (fn - n))];
         double rod[3];
         Mat3 Rt = tracker->R[i].t();
         rodrigues_m2v(Rt.m, rod);
@@ -324,32 +316,25 @@ void BundleAdjustmentBase::apply(Frame& f) {
         cam_frame.push_back(i);
         tr_opt.push_back(rod[0]); tr_opt.push_back(rod[1]); tr_opt.push_back(rod[2]);
         tr_opt.push_back(-tracker->t[i].v[0]); tr_opt.push_back(-tracker->t[i].v[1]); tr_opt.push_back(-tracker->t[i].v[2]);
-        const bool flat = frame->links_cover_map();   // the front-end's list holds the same entries in the same order
-        const size_t n_entries = flat ? frame->pnp_links.size() : 0;
-        auto entry = frame->map.begin();
-        for (size_t e = 0; flat ? e < n_entries : entry != frame->map.end(); flat ? (void)++e : (void)++entry) {
-            std::shared_ptr<Feature3D> f3d = flat ? frame->pnp_links[e].src_val->lock() : entry->second.lock();
-            if (!f3d) continue;
-            const int ft_column = flat ? frame->pnp_links[e].key_column : entry->first->column;
-            const int ft_row = flat ? frame->pnp_links[e].key_row : entry->first->row;
-            obs.push_back((double)ft_column); obs.push_back((double)ft_row);
-            // index of the landmark in first-seen order (p3d_opt of the reference); landmark ids are dense creation numbers
-            const size_t lid = (size_t)f3d->id;
-            if (lid >= seen_epoch.size()) { seen_epoch.resize(lid + 4096, 0); seen_index.resize(lid + 4096, 0); }
+        frame.for_each_feature([&](int e) {   // for (auto& p : frame->map)
+            const int id = frame.lm[(size_t)e];
+            if (L.expired(id)) return;
+            obs.push_back((double)frame.column[(size_t)e]); obs.push_back((double)frame.row[(size_t)e]);
+            // index of the landmark in first-seen order (the parameter blocks of the reference's problem, in the order they enter it)
             int pi;
-            if (seen_epoch[lid] != epoch) {
-                seen_epoch[lid] = epoch;
-                pi = (int)p3d_ptr.size();
-                seen_index[lid] = pi;
-                p3d_opt.push_back(f3d->x); p3d_opt.push_back(f3d->y); p3d_opt.push_back(f3d->z);
-                p3d_ptr.push_back(f3d.get());
-            } else pi = seen_index[lid];
+            if (seen_epoch[(size_t)id] != epoch) {
+                seen_epoch[(size_t)id] = epoch;
+                pi = (int)p3d_id.size();
+                seen_index[(size_t)id] = pi;
+                p3d_opt.push_back(L.xyz[3 * (size_t)id]); p3d_opt.push_back(L.xyz[3 * (size_t)id + 1]); p3d_opt.push_back(L.xyz[3 * (size_t)id + 2]);
+                p3d_id.push_back(id);
+            } else pi = seen_index[(size_t)id];
             obs_cam.push_back(ci); obs_pt.push_back(pi);
-        }
+        });
     }
     const int n_obs = (int)obs_cam.size();
     // Only parameter blocks that appear in a residual block are part of the Ceres problem: compact the cameras.
-    last_obs = (size_t)n_obs; last_points = p3d_ptr.size();
+    last_obs = (size_t)n_obs; last_points = p3d_id.size();
     std::vector<int> remap(cam_frame.size(), -1);
     std::vector<double> cams_c;
     cams_c.reserve(tr_opt.size());
@@ -362,10 +347,10 @@ void BundleAdjustmentBase::apply(Frame& f) {
         for (int& c : obs_cam) c = remap[c];
     }
     delete hpg;
-    tracker->stats.ba_calls++; tracker->stats.ba_obs += n_obs; tracker->stats.ba_points += (long)p3d_ptr.size();
+    tracker->stats.ba_calls++; tracker->stats.ba_obs += n_obs; tracker->stats.ba_points += (long)p3d_id.size();
     if (n_obs > 0) {
         const auto k0 = std::chrono::steady_clock::now();
-        ba_solve(cams_c.data(), nc, p3d_opt.data(), (int)p3d_ptr.size(), obs.data(), obs_cam.data(), obs_pt.data(), n_obs,
+        ba_solve(cams_c.data(), nc, p3d_opt.data(), (int)p3d_id.size(), obs.data(), obs_cam.data(), obs_pt.data(), n_obs,
                  tracker->camera, 1.0, tracker->cfg.ba_iterations);
         tracker->stats.t_ba_kernel += std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count();
     }
@@ -383,7 +368,7 @@ void BundleAdjustmentBase::apply(Frame& f) {
     }
     // (the reference repeats this loop once per window frame; Feature3D::update is a plain assignment, once is identical)
     if (!cam_frame.empty())
-        for (size_t p = 0; p < p3d_ptr.size(); p++) p3d_ptr[p]->update(p3d_opt[p * 3], p3d_opt[p * 3 + 1], p3d_opt[p * 3 + 2]);
+        for (size_t p = 0; p < p3d_id.size(); p++) L.put(p3d_id[p], Feature3D(p3d_opt[p * 3], p3d_opt[p * 3 + 1], p3d_opt[p * 3 + 2]));
 }
 
 // ---- OdometryPipeline ------------------------------------------------------------------------------------------------
@@ -431,7 +416,7 @@ void OdometryPipeline::initialise() {   // :428-482
                 f.column = roi[k].x * cfg.grid_size[1] + f.column;
                 f.row = roi[k].y * cfg.grid_size[0] + f.row;
                 s_i.push_back(f.score);
-                fr->map[std::make_shared<Feature>(f)] = std::weak_ptr<Feature3D>();
+                fr->add_feature(f.column, f.row, -1);   // fr->map[make_shared<Feature>(f)] = weak_ptr<Feature3D>()
             }
         }
         const double std_n = standardDeviation(n_i), std_s = standardDeviation(s_i);
@@ -451,36 +436,38 @@ void OdometryPipeline::initialise() {   // :428-482
 void OdometryPipeline::addFrame(Frame& frame) {   // :329-374
     HostCpuScope cpu_(stats.hp.t[12]);
     frame.frame = (int)frames.size();
+    Frame& prev = *(frames[frame.frame - 1]);
     const auto tl0 = std::chrono::steady_clock::now();
-    fmap feat_corr = matcher->matchFeatures(*(frames[frame.frame - 1]), frame);
+    fmap feat_corr = matcher->matchFeatures(prev, frame);
     stats.t_lk += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
-    stats.lk_calls++; stats.lk_points += (long)frames[frame.frame - 1]->map.size();
+    stats.lk_calls++; stats.lk_points += (long)prev.n_features();
     const int n_corr = (int)feat_corr.size();
-    frames[frame.frame - 1]->feat_corr = std::move(feat_corr);   // (the reference copies; the local is not used again)
-    index_feat_corr(*frames[frame.frame - 1]);
-    if (n_corr < cfg.tracked_features_tol) {
-        std::vector<GridSection> roi = getGridROI(*(frames[frames.size() - 1]));   // cells of the PREVIOUS frame (quirk Q3)
-        const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
-        std::vector<Frame> cells;
-        for (auto& r : roi) cells.push_back(r.frame);
-        const auto td0 = std::chrono::steady_clock::now();
-        std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
-        stats.t_detect += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
-        stats.detect_calls++;
-        NeighborGrid near(frame);   // frame.hasNeighbor(f) for every candidate, without the scan per candidate
-        for (size_t k = 0; k < roi.size(); k++)
-            for (auto& f : all[k]) {
-                if (!near.hasNeighbor(f.column, f.row)) {   // cell-LOCAL coordinates vs the global map (quirk Q4)
-                    f.column = roi[k].x * cfg.grid_size[1] + f.column;
-                    f.row = roi[k].y * cfg.grid_size[0] + f.row;
-                    frame.map[std::make_shared<Feature>(f)] = std::weak_ptr<Feature3D>();
-                    near.add(f.column, f.row);
-                }
-            }
-    }
+    prev.feat_corr = std::move(feat_corr);   // (the reference copies; the local is not used again)
+    redetect(prev, frame, n_corr);
     frames.push_back(std::make_shared<Frame>(std::move(frame)));   // (the reference copies; callers only read frame.frame afterwards)
-    // (no build_pnp_links here: in the one-thread schedule the lists would be built by the thread that then reads them - measured in the
-    // batched leg, 128 such threads: +77 us of host CPU per frame for building against -15 us for the gathers)
+}
+
+// the second half of addFrame (:342-371): new features when too few were tracked
+void OdometryPipeline::redetect(Frame& prev, Frame& frame, int n_corr) {
+    if (n_corr >= cfg.tracked_features_tol) return;
+    std::vector<GridSection> roi = getGridROI(prev);   // cells of the PREVIOUS frame (quirk Q3)
+    const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
+    std::vector<Frame> cells;
+    for (auto& r : roi) cells.push_back(r.frame);
+    const auto td0 = std::chrono::steady_clock::now();
+    std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
+    stats.t_detect += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
+    stats.detect_calls++;
+    NeighborGrid near(frame);   // frame.hasNeighbor(f) for every candidate, without the scan per candidate
+    for (size_t k = 0; k < roi.size(); k++)
+        for (auto& f : all[k]) {
+            if (!near.hasNeighbor(f.column, f.row)) {   // cell-LOCAL coordinates vs the global map (quirk Q4)
+                f.column = roi[k].x * cfg.grid_size[1] + f.column;
+                f.row = roi[k].y * cfg.grid_size[0] + f.row;
+                frame.add_feature(f.column, f.row, -1);   // frame.map[make_shared<Feature>(f)] = weak_ptr<Feature3D>()
+                near.add(f.column, f.row);
+            }
+        }
 }
 
 void OdometryPipeline::motionHeuristics(Mat3& _R, Vec3& _t, int j) {   // :171-208
@@ -510,7 +497,7 @@ void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     int n3d;
-    { HostProfScope h(stats.hp.t[7]); n3d = src.count3DPoints(); }
+    { HostProfScope h(stats.hp.t[7]); n3d = src.count3DPoints(landmarks); }
     const auto t0 = tnow();
     if (n3d >= cfg.tracked_features_tol) {
         pnpsolver->solvePnP(src, next, _R, _t);
@@ -607,33 +594,13 @@ void OdometryPipeline::run_threaded() {
         const auto tl0 = std::chrono::steady_clock::now();
         fmap feat_corr = matcher->matchFeatures(*prev, frame);
         stats.t_lk += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
-        stats.lk_calls++; stats.lk_points += (long)prev->map.size();
+        stats.lk_calls++; stats.lk_points += (long)prev->n_features();
         const int n_corr = (int)feat_corr.size();
         prev->feat_corr = std::move(feat_corr);
-        index_feat_corr(*prev);
-        if (triangulator) triangulator->prefetch(*prev);   // (prev, this frame) reaches the back-end one frame from now at the earliest
-        if (n_corr < cfg.tracked_features_tol) {
-            std::vector<GridSection> roi = getGridROI(*prev);
-            const int n_grid = (int)std::ceil((double)cfg.min_tracked_features / (double)roi.size());
-            std::vector<Frame> cells;
-            for (auto& r : roi) cells.push_back(r.frame);
-            const auto td0 = std::chrono::steady_clock::now();
-            std::vector<std::vector<Feature>> all = extractor->extractGrid(cells, n_grid);
-            stats.t_detect += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
-            stats.detect_calls++;
-            NeighborGrid near(frame);
-            for (size_t k = 0; k < roi.size(); k++)
-                for (auto& f : all[k])
-                    if (!near.hasNeighbor(f.column, f.row)) {
-                        f.column = roi[k].x * cfg.grid_size[1] + f.column;
-                        f.row = roi[k].y * cfg.grid_size[0] + f.row;
-                        frame.map[std::make_shared<Feature>(f)] = std::weak_ptr<Feature3D>();
-                        near.add(f.column, f.row);
-                    }
-        }
+        if (triangulator) triangulator->prefetch(*prev, frame);   // (prev, this frame) reaches the back-end one frame from now at the earliest
+        redetect(*prev, frame, n_corr);
         const int frame_no = frame.frame;
         std::shared_ptr<Frame> stored = std::make_shared<Frame>(std::move(frame));   // built outside the lock
-        build_pnp_links(*prev, *stored);   // the back-end reaches (prev, stored) after the next frame is in: nobody else touches either now
         {
             std::unique_lock<std::mutex> lk(mu);
             frames.push_back(std::move(stored));

@@ -15,7 +15,6 @@
 #include "vo_types.h"
 #include <functional>
 #include <chrono>
-#include <list>
 #include <mutex>
 #include <time.h>
 
@@ -107,7 +106,7 @@ public:
     // that many helper threads; triangulate() takes the finished result (or claims the job and computes it itself when no helper
     // has started it). Same function on the same points: identical E, mask and iteration count. Off for the hook form.
     int prefetch_threads = 0;
-    void prefetch(const Frame& prev) override;
+    void prefetch(const Frame& prev, const Frame& next) override;
     void finish() override;   // stops and joins the helper threads (jobs nobody asked for are dropped): nothing of this run touches the plugin hooks afterwards
     ~FivePointTri() override;
     // optional kernel hook for the RANSAC hypotheses of findEssentialMat: for n_hyp samples (5 indices each) of the n normalised
@@ -210,9 +209,9 @@ public:
     double camera[9];                       // row-major 3x3
     std::vector<ImageView> images;          // the sequence ("file_names"): decoded gray frames
     std::vector<Vec3> gt_t;                 // ground-truth positions (parsePoses), used for scale only (Q11)
-    // the reference keeps a std::vector and erases RANSAC outliers with std::find + erase (O(N) each, OpenCVEPnPSolver.cpp:47);
-    // a std::list with the node iterator stored in the landmark has the same content/order semantics at O(1) per erase
-    std::list<std::shared_ptr<Feature3D>> feats3d;
+    // feats3d of the reference (a vector of shared_ptr<Feature3D>, RANSAC outliers erased with std::find + erase,
+    // OpenCVEPnPSolver.cpp:47) as a table: id = creation number, liveness = "still in feats3d"
+    LandmarkTable landmarks;
     std::vector<std::shared_ptr<Frame>> frames;
     // guards the `frames` VECTOR (push_back by the front-end thread, element reads by the back-end thread: estimatePose's job
     // hand-over and BundleAdjustmentBase::apply's window). The Frame objects themselves are never touched by both threads at
@@ -226,12 +225,12 @@ public:
     BaseTriangulator* triangulator = nullptr;
     BaseOptimizer* ba = nullptr;
     Stats stats;
-    int next_landmark_id = 0;
 
     struct GridSection { int x, y; Frame frame; };
 
     void initialise();                                  // :428-482
     void addFrame(Frame& frame);                        // :329-374
+    void redetect(Frame& prev, Frame& frame, int n_corr);   // its second half (:342-371), shared by the two schedules
     void estimatePose(Frame& src, Frame& next);         // :376-426
     void motionHeuristics(Mat3& _R, Vec3& _t, int j);   // :171-208
     std::vector<GridSection> getGridROI(Frame& fr);     // :674-693

@@ -1,9 +1,13 @@
 // Host data model of the VO pipeline: OpenCV-free mirrors of the reference's Feature / Feature3D / Frame and of its
-// five plugin interfaces (the drop-in boundary).  Same names, argument meaning and container types as
+// five plugin interfaces (the drop-in boundary).  Same names and argument meaning as
 //   /root/reference/include/Feature.h, Feature3D.h, Frame.h, Base{FeatureExtractor,FeatureMatcher,PnPSolver,
 //   Triangulator,Optimizer}.h
-// so that iteration orders (libstdc++ unordered_map + Feature::Hasher + the same insertion sequence) are reproduced
-// exactly.  cv::Mat is replaced by Mat3 / Vec3 (row-major doubles).
+// The reference keeps a frame's features in std::unordered_map<shared_ptr<Feature>, weak_ptr<Feature3D>> / <weak_ptr, weak_ptr>
+// and its landmarks as shared_ptr<Feature3D>: a heap node, a control block and several atomic reference-count round trips per
+// feature and frame. Here they are TRACK TABLES - plain arrays per frame (coordinates, landmark id) and per run (landmark xyz,
+// liveness) - walked in exactly the order libstdc++ would walk the reference's containers (HashOrder: the same hash codes, the
+// same insertion sequence, the same bucket growth), because that order is part of the result. The tables are
+// what a device kernel can read as they are.  cv::Mat is replaced by Mat3 / Vec3 (row-major doubles).
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -12,7 +16,6 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
-#include <list>
 
 namespace vo {
 
@@ -45,9 +48,10 @@ inline Vec3 operator*(double s, const Vec3& a) { return Vec3{{s * a.v[0], s * a.
 
 // std::hash<std::string>{}(std::to_string(v)) memoised for the coordinate range features can take
 size_t coord_hash(int v);
+// Feature::Hasher (Feature.h:28-48) of a feature at (column, row): h1 ^ (h2 << 1)
+inline size_t feature_hash(int column, int row) { return coord_hash(column) ^ (coord_hash(row) << 1); }
 
-class Feature3D;
-// Feature.h:10-86
+// Feature.h:10-86 as a plain value: what an extractor returns. (Inside a Frame a feature is a row of the frame's tables, below.)
 class Feature {
 public:
     enum extractor { shi_tomasi, cv_good };
@@ -57,38 +61,8 @@ public:
     bool tracked = true;
     double score = 0;
     double displacement = 0;
-    // Host-side shortcuts (not in the reference, no effect on any result): where this feature's entries live in its frame's
-    // containers, so the back-end adapters do not hash/compare weak_ptr keys (several atomic reference-count round trips per
-    // lookup). Unordered-map nodes are address-stable; a null slot means "look it up as the reference does".
-    std::weak_ptr<Feature3D>* map_slot = nullptr;    // &frame.map[this] (set by the adapter that is about to use it)
-    std::weak_ptr<Feature>* corr_slot = nullptr;     // &frame.feat_corr[this] when THIS object is the entry's key (set by the front-end)
-    Feature* corr_feat = nullptr;                    // the feature *corr_slot refers to (frames, and with them their features, live for the whole run)
-    const void* map_owner = nullptr;                 // the container each slot points into: a slot is only used for that container
-    const void* corr_owner = nullptr;
-
     Feature(int column_, int row_) : row(row_), column(column_) {}
     Feature() { tracked = false; }
-
-    struct Hasher {   // Feature.h:28-48
-        std::size_t operator()(const std::weak_ptr<Feature>& f) const {
-            const std::shared_ptr<Feature> p = f.lock();   // one atomic round trip instead of expired() + lock()
-            if (!p) return 0;
-            return coord_hash(p->column) ^ (coord_hash(p->row) << 1);
-        }
-        std::size_t operator()(const std::shared_ptr<Feature>& f) const {
-            return coord_hash(f->column) ^ (coord_hash(f->row) << 1);
-        }
-    };
-    // Feature.cpp:48-55: coordinate equality for weak_ptr keys (expired keys never compare equal)
-    struct WeakEq {
-        bool operator()(const std::weak_ptr<Feature>& a, const std::weak_ptr<Feature>& b) const {
-            const std::shared_ptr<Feature> pa = a.lock();
-            if (!pa) return false;
-            const std::shared_ptr<Feature> pb = b.lock();
-            if (!pb) return false;
-            return pa->column == pb->column && pa->row == pb->row;
-        }
-    };
     // Feature.cpp:9-15 (Chebyshev distance)
     float distance(const Feature& f) const {
         int x = std::abs(column - f.column), y = std::abs(row - f.row);
@@ -96,12 +70,11 @@ public:
     }
 };
 
-// Feature3D.h:6-146 — the point is float32 at rest (cv::Point3f), arithmetic in double (quirk Q7)
+// Feature3D.h:6-146 - the point is float32 at rest (cv::Point3f), arithmetic in double (quirk Q7). The pipeline keeps its landmarks as
+// rows of a LandmarkTable (below); this value type carries the arithmetic of Feature3D.cpp:85-139 for one row.
 class Feature3D {
 public:
     float x, y, z;
-    int id = -1;   // creation order (explicit landmark id); not used by any arithmetic
-    std::list<std::shared_ptr<Feature3D>>::iterator self;   // position in OdometryPipeline::feats3d (O(1) erase)
     Feature3D(double x_, double y_, double z_) : x((float)x_), y((float)y_), z((float)z_) {}
     void rotate(const Mat3& R) {   // Feature3D.cpp:125-139
         double x0 = R.m[0] * x + R.m[1] * y + R.m[2] * z;
@@ -126,6 +99,65 @@ public:
     }
 };
 
+// The landmarks of a run: OdometryPipeline::feats3d (a vector of shared_ptr<Feature3D> in the reference) as a table. A landmark id
+// is its creation number; `alive[id]` is what `weak_ptr<Feature3D>::expired()` asks in the reference - the only owner of a landmark is
+// feats3d, and the only erase is the RANSAC-outlier erase of OpenCVEPnPSolver.cpp:40-49. Rows are plain arrays so that the same table
+// can be mirrored in HBM.
+struct LandmarkTable {
+    std::vector<float> xyz;          // 3 per landmark, float32 at rest (cv::Point3f)
+    std::vector<uint8_t> alive;
+    int n_alive = 0;                 // feats3d.size()
+    int size() const { return (int)alive.size(); }
+    int create(const Feature3D& p) { xyz.push_back(p.x); xyz.push_back(p.y); xyz.push_back(p.z); alive.push_back(1); n_alive++; return (int)alive.size() - 1; }
+    bool expired(int id) const { return id < 0 || !alive[(size_t)id]; }
+    void erase(int id) { if (alive[(size_t)id]) { alive[(size_t)id] = 0; n_alive--; } }
+    Feature3D get(int id) const { return Feature3D(xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]); }
+    void put(int id, const Feature3D& p) { xyz[3 * (size_t)id] = p.x; xyz[3 * (size_t)id + 1] = p.y; xyz[3 * (size_t)id + 2] = p.z; }
+};
+
+// Iteration order of a libstdc++ std::unordered_map (unique keys) for a given sequence of insertions, without the map: the
+// reference's results depend on the order in which Frame::map and Frame::feat_corr are WALKED (the order of the LK points, of the
+// PnP object points - RANSAC samples index into it - and of the BA residual blocks), and that order is a function of
+// the hash codes, the insertion sequence and the growth of the bucket array alone. This class replays exactly that function -
+// _Hashtable::_M_insert_unique_node / _M_insert_bucket_begin / _M_rehash_aux and the bucket counts of _Prime_rehash_policy, which
+// are read off a real std::unordered_map at start-up - over node indices: node i is the i-th inserted element; a lookup walks the
+// bucket's chain like _M_find_before_node. No allocation per node, no reference counts; the per-frame tables it orders are plain
+// arrays. Checked against the real container in tests/test_host_logic.py (random codes, collisions, growth through every prime)
+// and, end to end, against tests/twin/ref_twin.cpp, which keeps the reference's own containers.
+class HashOrder {
+public:
+    int size() const { return (int)next_.size(); }
+    int head() const { return head_; }                       // first node in iteration order, -1 when empty
+    int next(int node) const { return next_[(size_t)node]; }   // -1 after the last
+    size_t bucket_count() const { return nb_; }
+    void reserve_nodes(size_t n) { next_.reserve(n); code_.reserve(n); }
+    int insert(size_t code);                                 // a new node (the caller has made sure no equal key exists); returns its index
+    template <class Eq> int find(size_t code, Eq eq) const {  // node with this hash code for which eq(node) holds, or -1
+        const size_t bkt = code % nb_;
+        const int prev = bprev_.empty() ? EMPTY : bprev_[bkt];
+        if (prev == EMPTY) return -1;
+        int p = prev == BEFORE_BEGIN ? head_ : next_[(size_t)prev];
+        for (;;) {
+            if (code_[(size_t)p] == code && eq(p)) return p;
+            const int nx = next_[(size_t)p];
+            if (nx < 0 || code_[(size_t)nx] % nb_ != bkt) return -1;
+            p = nx;
+        }
+    }
+    // the nodes in iteration order
+    template <class F> void for_each(F f) const { for (int p = head_; p >= 0; p = next_[(size_t)p]) f(p); }
+    // bucket count of a std::unordered_map that started empty and now holds n elements (n insertions, no erase)
+    static size_t buckets_for(size_t n);
+private:
+    static constexpr int EMPTY = -1, BEFORE_BEGIN = -2;
+    std::vector<int> next_;       // per node
+    std::vector<size_t> code_;    // per node: cached hash code
+    std::vector<int> bprev_;      // per bucket: the node BEFORE the bucket's first node (BEFORE_BEGIN = the list head), EMPTY = no node
+    int head_ = -1;
+    size_t nb_ = 1;
+    void rehash(size_t n);
+};
+
 // Gray image view: host pixels (CPU plugins) and/or a device frame slot (HIP plugins). A grid cell is a sub-view that
 // shares the parent's storage (Frame::regionOfInterest, Frame.cpp:95-117).
 struct ImageView {
@@ -135,70 +167,75 @@ struct ImageView {
     int x0 = 0, y0 = 0, w = 0, h = 0;   // this view inside the full image
 };
 
-// Frame.h:12-105
-// One entry of Frame::map as OpenCVEPnPSolver's gather loop (OpenCVEPnPSolver.cpp:13-28) will meet it, as far as that is known once
-// the next frame exists (everything but whether the landmark is still alive): built by the front-end thread, which has the
-// features of both frames in cache, so that the back-end's loop is one pass over a flat list instead of a walk through the
-// hash-map nodes and feature objects of two frames (host-side shortcut like Feature::map_slot: no effect on any result).
-struct PnPLink {
-    std::weak_ptr<Feature3D>* src_val = nullptr;          // &entry.second: the landmark of the source feature
-    std::weak_ptr<Feature3D>* next_slot = nullptr;        // kind 1: &next.map[corresponding feature] (the node operator[] would reach)
-    const Feature* f = nullptr;                           // kind 1: the corresponding feature (its coordinates are the image point)
-    const std::shared_ptr<Feature>* key = nullptr;        // &entry.first (kind 2 runs the reference's lookups on it)
-    int key_column = 0, key_row = 0;                      // the entry's own feature (the observation CeresBundleAdjustment.cpp:28-33 reads)
-    unsigned char kind = 2;                               // 0 no correspondence; 1 as above; 2 same-pixel twin / absent node: the slow path, in sequence
+// BaseFeatureMatcher::fmap = unordered_map<weak_ptr<Feature>, weak_ptr<Feature>, Feature::Hasher> (BaseFeatureMatcher.h:13) and
+// Frame::feat_corr: source feature -> feature of the next frame. Keys compare by COORDINATES (Feature.cpp:48-55), so two source
+// features on the same pixel share one entry: the first stays the key, the last value wins. Entry n: key[n] = index of the source
+// feature in the source frame's table, val[n] = index in the next frame's table, -1 for the empty value operator[] leaves (quirk Q10).
+struct FeatureCorr {
+    std::vector<int> key, val;
+    HashOrder order;
+    size_t size() const { return key.size(); }
+    void clear() { key.clear(); val.clear(); order = HashOrder(); }
 };
-// One entry of Frame::feat_corr as OpenCVFivePointTri's gather loop (OpenCVFivePointTri.cpp:9-22) will meet it: both features and the
-// nodes of the two frames' maps that receive the triangulated landmark (:47-50). Built by the front-end like PnPLink.
-struct TriLink {
-    Feature* fst = nullptr; Feature* sec = nullptr;
-    std::weak_ptr<Feature3D>* src_slot = nullptr; std::weak_ptr<Feature3D>* next_slot = nullptr;
-};
+typedef FeatureCorr fmap;
 
+// Frame.h:12-105. Frame::map - unordered_map<shared_ptr<Feature>, weak_ptr<Feature3D>, Feature::Hasher> with POINTER equality, so
+// every inserted feature is its own entry, same pixel or not - as a table: feature e = (column[e], row[e]) -> landmark id lm[e]
+// (-1: the empty weak_ptr), walked in map_order's order.
 class Frame {
 public:
-    std::unordered_map<std::shared_ptr<Feature>, std::weak_ptr<Feature3D>, Feature::Hasher> map;
-    std::unordered_map<std::weak_ptr<Feature>, std::weak_ptr<Feature>, Feature::Hasher, Feature::WeakEq> feat_corr;
+    std::vector<int> column, row, lm;
+    HashOrder map_order;
+    FeatureCorr feat_corr;
     ImageView bw;
     int frame = 0;
-    std::vector<PnPLink> pnp_links;       // one per map entry, in iteration order; valid for solvePnP(*this, next) iff ...
-    const void* pnp_links_for = nullptr;  // ... == &next.map (a moved or copied frame has another address: self-invalidating)
-    std::vector<TriLink> tri_links;       // one per live feat_corr entry, in iteration order; valid under the same condition + ...
-    const void* tri_links_src = nullptr;  // ... == &map (of this frame)
-    bool links_cover_map() const { return pnp_links_for != nullptr && pnp_links.size() == map.size() && tri_links_src == (const void*)&map; }
 
     Frame() {}
     explicit Frame(const ImageView& img) : bw(img) {}
     bool isEmpty() const { return bw.w == 0; }
-    Frame regionOfInterest(int rx, int ry, int rw, int rh) const {   // Frame.cpp:95-117
+    int n_features() const { return (int)lm.size(); }                         // map.size()
+    int add_feature(int column_, int row_, int landmark) {                    // map[make_shared<Feature>(..)] = landmark
+        column.push_back(column_); row.push_back(row_); lm.push_back(landmark);
+        return map_order.insert(feature_hash(column_, row_));
+    }
+    template <class F> void for_each_feature(F f) const { map_order.for_each(f); }   // for (auto& p : map), p = feature index
+    // feat_corr.find(feature e of this frame): the entry whose key has e's coordinates, or -1
+    int corr_find(const FeatureCorr& c, int e) const {
+        const int col = column[(size_t)e], rw = row[(size_t)e];
+        return c.order.find(feature_hash(col, rw), [&](int n) { const int k = c.key[(size_t)n]; return column[(size_t)k] == col && row[(size_t)k] == rw; });
+    }
+    // feat_corr[feature e]: the entry (inserted with an empty value when absent: operator[])
+    int corr_at(FeatureCorr& c, int e) const {
+        int n = corr_find(c, e);
+        if (n < 0) { c.key.push_back(e); c.val.push_back(-1); n = c.order.insert(feature_hash(column[(size_t)e], row[(size_t)e])); }
+        return n;
+    }
+    Frame regionOfInterest(int rx, int ry, int rw, int rh) const {   // Frame.cpp:95-117 (a view of the pixels; no features)
         Frame f;
         f.bw = bw;
         f.bw.x0 = bw.x0 + rx; f.bw.y0 = bw.y0 + ry; f.bw.w = rw; f.bw.h = rh;
         return f;
     }
-    int count3DPoints() const {   // Frame.cpp:14-24
+    int count3DPoints(const LandmarkTable& L) const {   // Frame.cpp:14-24
         int c = 0;
-        if (links_cover_map()) { for (const PnPLink& L : pnp_links) if (!L.src_val->expired()) c++; }   // the same entries, from the flat list
-        else for (auto& p : map) if (!p.second.expired()) c++;
+        for (int id : lm) if (!L.expired(id)) c++;
         return c;
     }
     bool hasNeighbor(const Feature& f, int dist = 5) const {   // Frame.cpp:3-12
-        for (auto& p : map) if (f.distance(*p.first) < dist) return true;
+        for (size_t e = 0; e < lm.size(); e++) if (f.distance(Feature(column[e], row[e])) < dist) return true;
         return false;
     }
 };
 
-typedef std::unordered_map<std::weak_ptr<Feature>, std::weak_ptr<Feature>, Feature::Hasher, Feature::WeakEq> fmap;
-
 // Frame::hasNeighbor for many candidates against one (growing) feature set: the reference runs its O(N) scan per candidate
 // (OdometryPipeline.cpp:359-366, 2000 x 1350 distance evaluations per re-detection at configs[3]); an occupancy grid with
-// `dist`-sized buckets answers the same question — is there a feature with Chebyshev distance < dist — from the 3 x 3 buckets around
+// `dist`-sized buckets answers the same question - is there a feature with Chebyshev distance < dist - from the 3 x 3 buckets around
 // the candidate. Same boolean for every candidate, including features added while the loop runs (add()).
 class NeighborGrid {
 public:
     explicit NeighborGrid(const Frame& fr, int dist_ = 5) : dist(dist_) {
-        cells.reserve(fr.map.size() * 2 + 16);
-        for (auto& p : fr.map) add(p.first->column, p.first->row);
+        cells.reserve(fr.lm.size() * 2 + 16);
+        for (size_t e = 0; e < fr.lm.size(); e++) add(fr.column[e], fr.row[e]);
     }
     void add(int column, int row) { cells[key(bucket(column), bucket(row))].push_back({column, row}); }
     bool hasNeighbor(int column, int row) const {
@@ -249,10 +286,10 @@ class BaseTriangulator {
 public:
     virtual ~BaseTriangulator() {}
     virtual void triangulate(Frame& src, Frame& next, Mat3& R, Vec3& t) = 0;   // BaseTriangulator.h:20
-    // Called by the front-end thread of the two-thread pipeline as soon as `prev.feat_corr` (the correspondences prev -> the frame
-    // just tracked) is final. A triangulator may start whatever depends on nothing but these correspondences; the back-end reaches
-    // this frame pair at least one frame later. Default: nothing.
-    virtual void prefetch(const Frame& prev) { (void)prev; }
+    // Called by the front-end thread of the two-thread pipeline as soon as `prev.feat_corr` (the correspondences prev -> `next`, the
+    // frame just tracked) is final. A triangulator may start whatever depends on nothing but these correspondences; the back-end
+    // reaches this frame pair at least one frame later. Default: nothing.
+    virtual void prefetch(const Frame& prev, const Frame& next) { (void)prev; (void)next; }
     // End of the run (both pipeline threads are done): whatever prefetch() started must be finished or dropped before this returns.
     virtual void finish() {}
 };
