@@ -554,7 +554,7 @@ def main():
             stages.append(e)
     # detectors: §8d's B_det = W*H read + 8 B per corner written, per launch over the whole grid (what a fused pass moves)
     b_det = float(w * h) + 8.0 * cfg["min_tracked"]
-    for k_ in ("k_gftt_fused", "k_gftt_eig", "k_gftt_select"):
+    for k_ in ("k_gftt_cand", "k_gftt_pick"):
         stages.append(entry(k_, "hbm", b_det, PEAK_HBM_GBS, "GB/s", "B_det = W*H + 8 B/corner for the whole detector pass; every kernel of the pass is booked against it"))
     # PnP: FP64 VALU work of §8d, F_pnp = 40*iters*M + iters*EPnP(15 kflop), all of it in k_pnp_hyp (one wavefront per hypothesis)
     f_pnp = 40.0 * PNP_ITERS * pnp_m + PNP_ITERS * EPNP_FLOP

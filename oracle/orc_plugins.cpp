@@ -73,6 +73,11 @@ struct CpuLK : LucasKanadeFMBase {
     orc::Pool* pool = nullptr;   // fast mode (cpu_baseline timing): padded-buffer LK on a persistent pool, bit-identical results
     void pyrlk(const ImageView& prev, const ImageView& next, const float* prev_xy, int n, float* next_xy, uint8_t* status,
                float* err) override {
+        // EXPERIMENT (ORC_EXPERIMENT_LK_ROUND=1): the adapter truncates the sub-pixel LK result toward zero
+        // (OpenCVLucasKanadeFM.cpp:25); + 0.5 here turns that truncation into rounding, to see how much of the trajectory's
+        // heading drift the truncation explains. Never set in tests or benchmarks.
+        static const bool round_exp = getenv("ORC_EXPERIMENT_LK_ROUND") && atoi(getenv("ORC_EXPERIMENT_LK_ROUND")) != 0;
+        struct Rounder { float* xy; int n; bool on; ~Rounder() { if (on) for (int i = 0; i < 2 * n; i++) xy[i] += 0.5f; } } rounder{next_xy, n, round_exp};
         if (pool) {
             orc::LKParams P;
             orc::lk_track_fast(prev.host, next.host, prev.full_w, prev.full_h, prev_xy, n, P, next_xy, status, err, pool);

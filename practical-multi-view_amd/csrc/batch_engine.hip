@@ -278,7 +278,7 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
             int* dcnt = (int*)(dd + tot_out * 16) + c0;
             if (g.kind == 1)
                 EK(launch_gftt(s, ctx->d_slots, g.L, dc, g.n_cells, g.max_per_cell, g.quality, g.min_dist, g.unlimited, (float*)C.d_eig.p + c0 * CELL_PIX,
-                               (unsigned*)C.d_cellmax.p + c0, dxy, dcnt, C.d_flags, (unsigned*)C.d_spill.p + c0 * CELL_PIX));
+                               (unsigned*)C.d_cellmax.p + 2 * c0, dxy, dcnt, C.d_flags, (unsigned*)C.d_spill.p + c0 * CELL_PIX));
             else
                 EK(launch_shitomasi(s, ctx->d_slots, g.L, dc, g.n_cells, g.max_per_cell, g.quality, (double*)C.d_eig.p + c0 * CELL_PIX,
                                     (unsigned long long*)C.d_cellmax.p + c0, dxy, dsc, dcnt, C.d_flags, (unsigned*)C.d_spill.p + c0 * CELL_PIX));

@@ -455,9 +455,11 @@ int pmv_debug_gftt_response(pmv_ctx* ctx, int slot, const int* cell, float* out)
     int rc = check_cells(ctx, slot, cell, 1, 1);
     if (rc) return rc;
     REQ(out, PMV_ERR_INVALID, "null output");
-    int xy[2], cnt;
-    rc = pmv_detect_gftt(ctx, slot, cell, 1, 1, 0.01, 5.0, xy, &cnt);
-    if (rc) return rc;
+    CKC(hipSetDevice(ctx->device));
+    pack_cells(ctx->h_cells, cell, 1, slot);
+    CKC(hipMemcpyAsync(ctx->d_cells, ctx->h_cells, (size_t)CELL_STRIDE * 4, hipMemcpyHostToDevice, ctx->s_front));
+    CKC(launch_gftt_response(ctx->s_front, ctx->d_slots, ctx->slot_layout[slot], ctx->d_cells, 1, (float*)ctx->d_eig, (unsigned*)ctx->d_cellmax));
+    CKC(hipStreamSynchronize(ctx->s_front));
     CKC(hipMemcpy(out, ctx->d_eig, (size_t)cell[2] * cell[3] * sizeof(float), hipMemcpyDeviceToHost));
     return PMV_OK;
 }

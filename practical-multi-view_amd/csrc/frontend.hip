@@ -661,104 +661,224 @@ __global__ __launch_bounds__(256) void k_gftt_eig(const uint8_t* __restrict__ sl
     }
 }
 
-// Phase 2: threshold (TOZERO at quality*max), 3x3 NMS, then greedy min-distance selection in descending
-// (value, address) order. The sequential OpenCV loop "walk the sorted list, accept a corner unless an accepted one is
-// closer than minDistance" is evaluated as: repeat {arg-max over live candidates; accept; kill every candidate closer
-// than minDistance} — identical result, max_corners rounds, no sort.
-constexpr int GFTT_CAP = 16384;
-constexpr size_t GFTT_SELECT_SHM = GFTT_CAP * 8 + 16 * 8 + 16;
-__global__ __launch_bounds__(1024) void k_gftt_select(const int* __restrict__ cells, const float* __restrict__ eig,
-                                                      const unsigned* __restrict__ cellmax, int max_corners,
-                                                      double quality, double min_dist, int unlimited, int* __restrict__ out_xy,
-                                                      int* __restrict__ out_count, int* __restrict__ flags, unsigned* __restrict__ spill_all) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // candidates 0..GFTT_CAP-1 live in LDS; a cell with more (a periodic texture can make every pixel a 3x3 maximum) keeps the rest in
-    // HBM as pixel indices (value = the thresholded response at that pixel, bit 31 = dead): no candidate list can overflow
-    unsigned* spill = spill_all + (size_t)blockIdx.x * CELL_PIX;
-    float* cval = (float*)smem;                       // GFTT_CAP
-    unsigned* cidx = (unsigned*)(smem + GFTT_CAP * 4); // GFTT_CAP
-    unsigned long long* wbest = (unsigned long long*)(smem + GFTT_CAP * 8);  // 16
-    int* scount = (int*)(smem + GFTT_CAP * 8 + 16 * 8);
-    const int cell = blockIdx.x;
-    const int cw = cells[CELL_STRIDE * cell + 2], ch = cells[CELL_STRIDE * cell + 3];
-    const float* E = eig + (size_t)cell * CELL_PIX;
-    const int tid = threadIdx.x;
-    if (tid == 0) *scount = 0;
+// ---- the detector pass proper: no response map in HBM -------------------------------------------------------------------------------
+// cov = (dx^2, dx dy, dy^2) at one cell position (the Sobel arithmetic of k_gftt_eig, shared)
+__device__ inline void gftt_cov(const uint8_t* __restrict__ p, int st, float& c0, float& c1, float& c2) {
+    const float k1 = (float)(1.0 / 3060.0), k2 = (float)(2.0 / 3060.0);
+    const float p00 = p[-st - 1], p01 = p[-st], p02 = p[-st + 1];
+    const float p10 = p[-1], p12 = p[1];
+    const float p20 = p[st - 1], p21 = p[st], p22 = p[st + 1];
+    const float rt = p02 - p00, rm = p12 - p10, rb = p22 - p20;
+    const float dx = (rt + rb) * k1 + rm * k2;
+    float s_t = k1 * p00; s_t += k2 * p01; s_t += k1 * p02;
+    float s_b = k1 * p20; s_b += k2 * p21; s_b += k1 * p22;
+    const float dy = s_b - s_t;
+    c0 = dx * dx; c1 = dx * dy; c2 = dy * dy;
+}
+// Pass 1, grid = (tiles_x, tiles_y, n_cells), 256 threads, 32x32 cell pixels per workgroup: covariances on the 36x36 halo, min-eigenvalue
+// on 34x34, then the 3x3 non-maximum test on the RAW response and one (value, pixel) record per surviving pixel. The reference's order is
+// threshold -> dilate -> compare; for a pixel above the threshold the thresholded neighbours exceed it exactly when the raw ones do
+// (a neighbour at or below the threshold became 0), so the test needs no threshold - which is only known once the whole cell has been
+// seen (0.01 x the cell's maximum, cellinfo[2 cell] by atomicMax). Pass 2 drops the records at or below it. Only values > 0 can ever be
+// selected. HBM traffic: the cell's pixels once (+ halo), 8 B per local maximum - no 4 W H map.
+__global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ slots, PyrLayout L, const int* __restrict__ cells,
+                                                   float* __restrict__ cand_val, unsigned* __restrict__ cand_idx, unsigned* __restrict__ cellinfo) {
+    __shared__ float sC[36 * 36 * 3];
+    __shared__ float sE[34 * 34];
+    __shared__ unsigned smax[4];
+    const int cell = blockIdx.z;
+    const int cx0 = cells[CELL_STRIDE * cell], cy0 = cells[CELL_STRIDE * cell + 1], cw = cells[CELL_STRIDE * cell + 2], ch = cells[CELL_STRIDE * cell + 3];
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+    if (tx0 >= cw || ty0 >= ch) return;
+    const uint8_t* img = level_origin(slots + (size_t)cells[CELL_STRIDE * cell + 4] * L.slot_bytes, L, 0);
+    const int st = L.stride[0];
+    for (int idx = threadIdx.x; idx < 36 * 36; idx += 256) {
+        const int hy = idx / 36, hx = idx - hy * 36;
+        // the box filter's border is the CELL's (REFLECT_101 of the cell coordinate); the Sobel's is the parent image's (= the padded level)
+        const int lx = reflect101(tx0 - 2 + hx, cw), ly = reflect101(ty0 - 2 + hy, ch);
+        gftt_cov(img + (ptrdiff_t)(cy0 + ly) * st + (cx0 + lx), st, sC[idx * 3], sC[idx * 3 + 1], sC[idx * 3 + 2]);
+    }
     __syncthreads();
-    const double maxVal = (double)f32_unkey(cellmax[cell]);
-    const float thr = (float)(maxVal * quality);
-    const int iw = cw - 2, ih = ch - 2;
-    for (int idx = tid; idx < iw * ih; idx += 1024) {
-        const int y = idx / iw + 1, x = idx - (y - 1) * iw + 1;
-        const float raw = E[y * cw + x];
-        const float v = raw > thr ? raw : 0.f;
-        if (v == 0.f) continue;
-        bool ismax = true;
+    unsigned mk = 0;   // key 0 is below every real float key
+    for (int idx = threadIdx.x; idx < 34 * 34; idx += 256) {
+        const int ey = idx / 34, ex = idx - ey * 34;
+        const int x = tx0 - 1 + ex, y = ty0 - 1 + ey;
+        float e = -1.f;   // outside the cell: never consulted (only interior pixels are tested), never counted in the maximum
+        if (x >= 0 && y >= 0 && x < cw && y < ch) {
+            double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-        for (int j = -1; j <= 1; j++)
+            for (int j = 0; j < 3; j++)
 #pragma unroll
-            for (int i = -1; i <= 1; i++) {
-                const float nr = E[(y + j) * cw + x + i];
-                const float nv = nr > thr ? nr : 0.f;
-                ismax = ismax && !(nv > v);
+                for (int i = 0; i < 3; i++) {
+                    const float* c = &sC[((ey + j) * 36 + (ex + i)) * 3];
+                    s0 += c[0]; s1 += c[1]; s2 += c[2];
+                }
+            const float a = (float)s0 * 0.5f, b = (float)s1, c2 = (float)s2 * 0.5f;
+            e = (a + c2) - sqrtf((a - c2) * (a - c2) + b * b);
+            if (ex >= 1 && ex <= 32 && ey >= 1 && ey <= 32 && e == e) { const unsigned k = f32_key(e); mk = k > mk ? k : mk; }   // every cell pixel once
+        }
+        sE[idx] = e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(mk, o, 64); mk = t > mk ? t : mk; }
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = smax[0];
+        for (int i = 1; i < 4; i++) m = smax[i] > m ? smax[i] : m;
+        atomicMax(&cellinfo[2 * cell], m);
+    }
+    // the tile's records are collected in LDS first (sC is free now), then ONE global atomic per workgroup reserves their place in the
+    // cell's list (640 workgroups bumping 10 counters per wavefront and turn serialised in L2: 82 us per launch instead of 15)
+    unsigned* s_cnt = smax;                          // [0] tile count, [1] base in the cell's list (smax has been read by thread 0 only)
+    float* lv = sC;                                  // up to 1024 values ...
+    unsigned* li = (unsigned*)(sC + 1024);           // ... and pixel indices
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt[0] = 0;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {   // (every lane takes all four turns: the ballot below is wave-wide)
+        const int oy = idx >> 5, ox = idx & 31;
+        const int x = tx0 + ox, y = ty0 + oy;
+        bool cand = false;
+        float v = 0.f;
+        if (x >= 1 && y >= 1 && x < cw - 1 && y < ch - 1) {
+            v = sE[(oy + 1) * 34 + ox + 1];
+            cand = v > 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) cand = cand && !(sE[(oy + j) * 34 + ox + i] > v);
+        }
+        const unsigned long long bal = __ballot(cand);
+        if (bal) {   // one LDS atomic per wavefront
+            const int lane = threadIdx.x & 63;
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[0], (unsigned)__popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (cand) {
+                const unsigned slot = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                lv[slot] = v; li[slot] = (unsigned)(y * cw + x);
             }
-        if (ismax) {
-            const int slot = atomicAdd(scount, 1);
-            if (slot < GFTT_CAP) { cval[slot] = v; cidx[slot] = (unsigned)(y * cw + x); }
-            else spill[slot - GFTT_CAP] = (unsigned)(y * cw + x);
         }
     }
-    __threadfence_block();
     __syncthreads();
-    const int ncand = *scount;
+    const unsigned nt = s_cnt[0];
+    if (nt == 0) return;
+    if (threadIdx.x == 0) s_cnt[1] = atomicAdd(&cellinfo[2 * cell + 1], nt);
+    __syncthreads();
+    const unsigned gbase = s_cnt[1];
+    float* cv = cand_val + (size_t)cell * CELL_PIX + gbase;
+    unsigned* ci = cand_idx + (size_t)cell * CELL_PIX + gbase;
+    for (unsigned i = threadIdx.x; i < nt; i += 256) { cv[i] = lv[i]; ci[i] = li[i]; }
+}
+
+// Pass 2, one 256-thread workgroup per cell: records above the threshold are compacted into LDS and dealt to the lanes' REGISTERS; the
+// greedy selection of cv::goodFeaturesToTrack ("walk the list sorted by (value, address) descending, accept a corner unless an accepted
+// one is closer than minDistance") runs as: repeat {arg-max over the live records; accept; kill every record closer than minDistance} -
+// identical result, max_corners rounds of register work with one 4-wavefront exchange each, no sort. A cell with more than GP_REG records
+// above the threshold (a periodic texture can make every pixel a local maximum) takes the same rounds over its list in HBM.
+constexpr int GP_T = 256, GP_SLOTS = 16, GP_REG = GP_T * GP_SLOTS;
+__global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cells, float* __restrict__ cand_val, unsigned* __restrict__ cand_idx,
+                                                    const unsigned* __restrict__ cellinfo, int max_corners, double quality, double min_dist,
+                                                    int unlimited, int* __restrict__ out_xy, int* __restrict__ out_count, int* __restrict__ flags) {
+    __shared__ unsigned long long lkey[GP_REG];
+    __shared__ unsigned long long wbest[2][4];
+    const int cell = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cw = cells[CELL_STRIDE * cell + 2];
+    float* cv = cand_val + (size_t)cell * CELL_PIX;
+    unsigned* ci = cand_idx + (size_t)cell * CELL_PIX;
+    const int nraw = (int)cellinfo[2 * cell + 1];
+    const double maxVal = (double)f32_unkey(cellinfo[2 * cell]);
+    const float thr = (float)(maxVal * quality);
+    // compaction of the records above the threshold: key = (value bits, pixel index), 0 = dead. The first GP_REG go to LDS, the rest
+    // stay in the HBM list, compacted in place (a record only moves to a lower position, behind every record already read)
+    int n = 0;
+    for (int base = 0; base < nraw; base += GP_T) {
+        const int i = base + tid;
+        float v = 0.f; unsigned px = 0;
+        if (i < nraw) { v = cv[i]; px = ci[i]; }
+        const bool keep = i < nraw && v > thr;
+        __syncthreads();   // (all reads of this chunk before any in-place write into it)
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wbest[0][wave] = (unsigned long long)__popcll(bal);
+        __syncthreads();
+        int off = n;
+        for (int w2 = 0; w2 < wave; w2++) off += (int)wbest[0][w2];
+        const int tot = (int)(wbest[0][0] + wbest[0][1] + wbest[0][2] + wbest[0][3]);
+        if (keep) {
+            const int slot = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (slot < GP_REG) lkey[slot] = ((unsigned long long)__float_as_uint(v) << 32) | px;
+            else { cv[slot] = v; ci[slot] = px; }
+        }
+        n += tot;
+    }
+    __syncthreads();
     const bool use_dist = min_dist >= 1.0;
     const double md2 = min_dist * min_dist;
+    // dx*dx + dy*dy is an integer: (double)d2 < md2  <=>  d2 < ceil(md2)
+    const int md2i = (int)(md2 < 2.0e9 ? ceil(md2) : 2.0e9);
+    const int n_reg = n < GP_REG ? n : GP_REG;
+    unsigned long long key[GP_SLOTS];
+    int kxy[GP_SLOTS];   // (y << 16) | x of the slot's pixel: the divisions by the cell width happen once, not in every round
+#pragma unroll
+    for (int s2 = 0; s2 < GP_SLOTS; s2++) {
+        const int i = s2 * GP_T + tid;
+        key[s2] = i < n_reg ? lkey[i] : 0ull;
+        const int px = (int)(key[s2] & 0x7fffffffu);
+        const int y = px / cw;
+        kxy[s2] = (y << 16) | (px - y * cw);
+    }
     int naccepted = 0;
     for (int it = 0; it < max_corners; it++) {
         unsigned long long best = 0;
-        for (int i = tid; i < ncand; i += 1024) {
-            float v; unsigned ci;
-            if (i < GFTT_CAP) { v = cval[i]; ci = cidx[i]; }   // dead candidates are marked with -1
-            else { ci = spill[i - GFTT_CAP]; v = (ci >> 31) ? -1.f : E[ci]; }
-            if (v > 0.f) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | ci;
-                best = key > best ? key : best;
-            }
+#pragma unroll
+        for (int s2 = 0; s2 < GP_SLOTS; s2++) best = key[s2] > best ? key[s2] : best;
+        for (int i = GP_REG + tid; i < n; i += GP_T) {   // (only for cells beyond the register capacity)
+            const unsigned px = ci[i];
+            if (!(px >> 31)) { const unsigned long long k = ((unsigned long long)__float_as_uint(cv[i]) << 32) | px; best = k > best ? k : best; }
         }
         best = wave_max_u64(best);
-        if ((tid & 63) == 0) wbest[tid >> 6] = best;
-        __syncthreads();
-        unsigned long long b = wbest[0];
+        if (lane == 0) wbest[it & 1][wave] = best;
+        __syncthreads();   // (one barrier per round: the exchange buffer alternates)
+        unsigned long long b = wbest[it & 1][0];
 #pragma unroll
-        for (int i = 1; i < 16; i++) b = wbest[i] > b ? wbest[i] : b;
+        for (int i = 1; i < 4; i++) b = wbest[it & 1][i] > b ? wbest[it & 1][i] : b;
         if (b == 0) break;
-        const int bidx = (int)(b & 0xffffffffu);
+        const int bidx = (int)(b & 0x7fffffffu);
         const int by = bidx / cw, bx = bidx - by * cw;
         if (tid == 0) {
             out_xy[((size_t)cell * max_corners + naccepted) * 2] = bx;
             out_xy[((size_t)cell * max_corners + naccepted) * 2 + 1] = by;
         }
         naccepted++;
-        for (int i = tid; i < ncand; i += 1024) {
-            int ci;
-            if (i < GFTT_CAP) { if (cval[i] <= 0.f) continue; ci = (int)cidx[i]; }
-            else { const unsigned u = spill[i - GFTT_CAP]; if (u >> 31) continue; ci = (int)u; }
+#pragma unroll
+        for (int s2 = 0; s2 < GP_SLOTS; s2++) {
             bool kill;
             if (use_dist) {
-                const int y = ci / cw, x = ci - y * cw;
+                const int dx = (kxy[s2] & 0xffff) - bx, dy = (kxy[s2] >> 16) - by;
+                kill = dx * dx + dy * dy < md2i;
+            } else kill = (int)(key[s2] & 0x7fffffffu) == bidx;
+            if (kill) key[s2] = 0;
+        }
+        for (int i = GP_REG + tid; i < n; i += GP_T) {
+            const unsigned u = ci[i];
+            if (u >> 31) continue;
+            bool kill;
+            if (use_dist) {
+                const int y = (int)u / cw, x = (int)u - y * cw;
                 const int dx = x - bx, dy = y - by;
                 kill = (double)(dx * dx + dy * dy) < md2;
-            } else kill = ci == bidx;
-            if (kill) { if (i < GFTT_CAP) cval[i] = -1.f; else spill[i - GFTT_CAP] = (unsigned)ci | 0x80000000u; }
+            } else kill = (int)u == bidx;
+            if (kill) ci[i] = u | 0x80000000u;
         }
-        __threadfence_block();
-        __syncthreads();
     }
     // cv::goodFeaturesToTrack(maxCorners <= 0) has no limit; here the caller's buffer holds max_corners: more corners than that
     // is reported (bit 2), not silently truncated
     if (unlimited && naccepted == max_corners) {
         int live = 0;
-        for (int i = tid; i < ncand; i += 1024) live |= i < GFTT_CAP ? (cval[i] > 0.f) : !(spill[i - GFTT_CAP] >> 31);
+#pragma unroll
+        for (int s2 = 0; s2 < GP_SLOTS; s2++) live |= key[s2] != 0;
+        for (int i = GP_REG + tid; i < n; i += GP_T) live |= !(ci[i] >> 31);
         if (live) atomicOr(flags, 4);
     }
     if (tid == 0) out_count[cell] = naccepted;
@@ -768,14 +888,22 @@ hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, 
                        int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,
                        int* d_out_xy, int* d_out_count, int* d_flags, unsigned* d_spill) {
     if (!slots || !d_cells || !d_eig || !d_cellmax || !d_out_xy || !d_out_count || !d_flags || !d_spill || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(d_cellmax, 0, sizeof(unsigned) * n_cells, s);
+    // d_eig / d_spill: the cells' candidate records (value / pixel index, CELL_PIX each); d_cellmax: (maximum key, record count) per cell
+    hipError_t e = hipMemsetAsync(d_cellmax, 0, 2 * sizeof(unsigned) * n_cells, s);
     if (e != hipSuccess) return e;
-    { ProfScope ps(K_GFTT_EIG, s);
-    hipLaunchKernelGGL(k_gftt_eig, dim3(8, 8, n_cells), dim3(256), 0, s, slots, L, d_cells, d_eig, d_cellmax); }
-    ProfScope ps2(K_GFTT_SELECT, s);
-    const size_t shm = GFTT_SELECT_SHM;   // opt-in above 64 KB: frontend_prepare_device(), once per context on its device
-    hipLaunchKernelGGL(k_gftt_select, dim3(n_cells), dim3(1024), shm, s, d_cells, d_eig, d_cellmax, max_per_cell,
-                       quality, min_dist, unlimited, d_out_xy, d_out_count, d_flags, d_spill);
+    { ProfScope ps(K_GFTT_CAND, s);
+    hipLaunchKernelGGL(k_gftt_cand, dim3(8, 8, n_cells), dim3(256), 0, s, slots, L, d_cells, d_eig, d_spill, d_cellmax); }
+    ProfScope ps2(K_GFTT_PICK, s);
+    hipLaunchKernelGGL(k_gftt_pick, dim3(n_cells), dim3(GP_T), 0, s, d_cells, d_eig, d_spill, d_cellmax, max_per_cell,
+                       quality, min_dist, unlimited, d_out_xy, d_out_count, d_flags);
+    return hipGetLastError();
+}
+// diagnostic / parity: the response map itself (pmv_debug_gftt_response), which the detector pass no longer writes
+hipError_t launch_gftt_response(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells, float* d_eig, unsigned* d_cellmax) {
+    if (!slots || !d_cells || !d_eig || !d_cellmax || n_cells < 1) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_cellmax, 0, 2 * sizeof(unsigned) * n_cells, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gftt_eig, dim3(8, 8, n_cells), dim3(256), 0, s, slots, L, d_cells, d_eig, d_cellmax);
     return hipGetLastError();
 }
 
@@ -931,8 +1059,6 @@ hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slots, const PyrLayout
 // Kernels that need more than the default 64 KB of dynamic LDS opt in per DEVICE (function attributes are per device in HIP):
 // called by pmv_ctx_create after hipSetDevice, so a second context on another GPU of the same process is set up as well.
 hipError_t frontend_prepare_device() {
-    hipError_t e = hipFuncSetAttribute((const void*)k_gftt_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GFTT_SELECT_SHM);
-    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_st_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_SELECT_SHM);
 }
 

@@ -122,6 +122,7 @@ hipError_t launch_shitomasi(hipStream_t s, const uint8_t* slots, const PyrLayout
                             int max_per_cell, double quality, double* d_resp, unsigned long long* d_cellmax,
                             int* d_out_xy, double* d_out_score, int* d_out_count, int* d_flags, unsigned* d_spill);
 
+hipError_t launch_gftt_response(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells, float* d_eig, unsigned* d_cellmax);
 constexpr int CELL_MAX = 255;                 // OdometryPipeline.h:31 grid_size
 constexpr int CELL_PIX = CELL_MAX * CELL_MAX;
 

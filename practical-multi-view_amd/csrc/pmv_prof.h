@@ -6,11 +6,11 @@
 
 namespace pmv {
 
-enum KernelId { K_PAD0 = 0, K_PYRDOWN, K_LK, K_GFTT_EIG, K_GFTT_SELECT, K_ST_RESP, K_ST_SELECT, K_PNP_HYP, K_PNP_REFIT,
+enum KernelId { K_PAD0 = 0, K_PYRDOWN, K_LK, K_GFTT_CAND, K_GFTT_PICK, K_ST_RESP, K_ST_SELECT, K_PNP_HYP, K_PNP_REFIT,
                 K_BA_LM, K_BA_RESID, K_TRI_DLT, K_BAM_EVAL0, K_BAM_CAMPOINT, K_BAM_GEMM, K_BAM_SOLVE, K_BAM_BACKSUB, K_BAM_FINISH, K_FIVEPOINT, K_COUNT };
 
 inline const char* kernel_name(int id) {
-    static const char* n[K_COUNT] = {"k_pad_level0", "k_pyrdown", "k_lk", "k_gftt_eig", "k_gftt_select", "k_st_resp", "k_st_select",
+    static const char* n[K_COUNT] = {"k_pad_level0", "k_pyrdown", "k_lk", "k_gftt_cand", "k_gftt_pick", "k_st_resp", "k_st_select",
                                      "k_pnp_hyp", "k_pnp_select_refit", "ba_lm_chain", "k_ba_residuals", "k_tri_dlt",
                                      "k_bam_eval0", "k_bam_campoint", "k_bam_gemm", "k_bam_solve", "k_bam_backsub", "k_bam_finish", "k_fivepoint_hyp+score"};
     return (id >= 0 && id < K_COUNT) ? n[id] : "?";
