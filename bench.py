@@ -110,8 +110,8 @@ def main():
     ap.add_argument("--tri-threads", type=int, default=8, help="host threads evaluating the triangulator's five-point RANSAC hypotheses")
     ap.add_argument("--kitti-seq", default="07", help="sequence used when KITTI_ROOT points at a KITTI odometry tree (default: synthetic data)")
     ap.add_argument("--poses-out", default="", help="write the estimated poses of the last step in KITTI format")
-    ap.add_argument("--batch", type=int, default=128, help="batched leg: B independent sequences through batched launches on each GPU (0 = skip); "
-                                                           "128 sequences of the metric config are 222 GB of frame slots (sized for 288 GB of HBM)")
+    ap.add_argument("--batch", type=int, default=192, help="batched leg: B independent sequences through batched launches on each GPU (0 = skip); "
+                                                           "192 sequences of the metric config are 234 GB of frame slots (sized for 288 GB of HBM)")
     ap.add_argument("--batch-distinct", type=int, default=16, help="distinct sequences (4 seeds x start offsets) cycled over the B slots of the batched leg")
     ap.add_argument("--batch-contexts", type=int, default=0, help="diagnostic: also run the round-1 form (B contexts x 2 host threads x 2 streams)")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the hbm_resident leg (frames already staged in HBM)")
@@ -373,14 +373,15 @@ def main():
         while bc is None:
             try:
                 bc = pmv.Context(w, h, **dict(ctx_kw, n_slots=B * n, max_tracks=1024, max_ba_cams=8, max_ba_points=4096, max_ba_obs=32768))
-            except pmv.PmvError:      # not enough free HBM for B sequences: halve
+            except pmv.PmvError:      # not enough free HBM for B sequences: fewer
                 if B <= 8:
                     raise
-                B //= 2
+                B = B - 32 if B > 64 else B // 2
         for b in range(B):
             bc.frames_stage(b * n, distinct[b % D][0])   # every slot range holds its own copy (B sequences = B x 1.7 GB of HBM, as real data would)
         bseqs = [(b * n, n, distinct[b % D][1]) for b in range(B)]
-        warm = bc.pipeline_run_batch(bseqs, w, h, K, threaded=0, **batch_kw)
+        bthr = 0 if args.sequential else 1   # per sequence: the reference's front-end / back-end threads (two requests in flight) or one thread
+        warm = bc.pipeline_run_batch(bseqs, w, h, K, threaded=bthr, **batch_kw)
         bc.sync()
         s0 = bc.batch_stats()
         bc.lk_counters(reset=True)
@@ -388,7 +389,7 @@ def main():
             dist.barrier()
         t1 = time.perf_counter()
         c1 = time.process_time()
-        results = bc.pipeline_run_batch(bseqs, w, h, K, threaded=0, **batch_kw)
+        results = bc.pipeline_run_batch(bseqs, w, h, K, threaded=bthr, **batch_kw)
         bc.sync()
         dtb = time.perf_counter() - t1
         cpu_b = time.process_time() - c1
@@ -401,7 +402,7 @@ def main():
         if rank == 0:
             # kernel table of the batched launches: a third pass with per-launch events on (they cost host time, so not in the timed pass)
             bc.prof_enable(True)
-            prof_pass = bc.pipeline_run_batch(bseqs, w, h, K, threaded=0, **batch_kw)
+            prof_pass = bc.pipeline_run_batch(bseqs, w, h, K, threaded=bthr, **batch_kw)
             bc.sync()
             bc.prof_enable(False)
             bprof = bc.prof_read()
@@ -432,11 +433,11 @@ def main():
                            n_gpus=world, per_gpu=round(tot_frames / max_sec / world, 3), identical_to_single_run=bool(all_same),
                            distinct_how=f"{n_seed} seeds x start offsets 0/{OFF}/{2 * OFF}/{3 * OFF} frames, cycled over the {B} slot ranges; every batched result "
                                         f"is compared bitwise with the single-sequence run of the same input",
-                           host_threads=B + 5, host_cpu_us_per_frame=round(cpu_b / fr_b * 1e6, 1), host_cores_busy=round(cpu_b / dtb, 2),
+                           host_threads=(2 if bthr else 1) * B + 6, host_cpu_us_per_frame=round(cpu_b / fr_b * 1e6, 1), host_cores_busy=round(cpu_b / dtb, 2),
                            frame_rate_roofline=dict(frac=sum(stage_b.values()) / dtb, stage_seconds={k_: round(v, 6) for k_, v in stage_b.items()},
                                                     measured_seconds=round(dtb, 4), note="rank 0's pass: sum over its B sequences of stage(algorithmic / peak) / measured time"),
                            combiners=rounds, kernels=bk, roofline=b_roof, input_generation_s=round(t_gen_b, 2),
-                           how="pmv_pipeline_run_batch on every rank: one host thread per sequence (unchanged adapters), five combiner threads merge the plugin "
+                           how="pmv_pipeline_run_batch on every rank: front-end + back-end host thread per sequence (unchanged adapters), combiner threads merge the plugin "
                                "calls into batched launches (k_lk_batch, detectors, k_pnp_*_batch, k_bamB_* chain, k_tri_dlt_batch), one HIP stream per class; "
                                "value = frames of all ranks / slowest rank's time")
         for r_ in warm + results:

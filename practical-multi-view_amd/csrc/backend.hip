@@ -11,7 +11,7 @@ namespace pmv {
 
 // Input block of a solve from mapped pinned host memory into HBM: a copy launch on the solve's own stream instead of a DMA-engine
 // transfer (hipMemcpyAsync of ~50 KB goes through SDMA: 10-15 us until the first kernel of the chain may start; this is ~5).
-__global__ __launch_bounds__(256) void k_stage_block(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned n16) {
+__global__ __launch_bounds__(256) void k_stage_block(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned n16) { BACKEND_PRIO();
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 

@@ -172,7 +172,7 @@ __device__ inline void projection_residual(const double* cam, const double* X, d
 __global__ __launch_bounds__(256) void k_ba_residuals(const double* __restrict__ cams, const double* __restrict__ pts,
                                                       const double* __restrict__ obs, const int* __restrict__ cam_idx,
                                                       const int* __restrict__ pt_idx, int nobs, const double* __restrict__ K,
-                                                      double* __restrict__ out_r, double* __restrict__ out_J) {
+                                                      double* __restrict__ out_r, double* __restrict__ out_J) { BACKEND_PRIO();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nobs) return;
     double r[2], Jc[12], Jp[6];
@@ -273,7 +273,7 @@ __device__ inline v4d cam_block_mfma(const double* __restrict__ J, const double*
     return acc;   // D[row = (lane>>4) + 4*reg][col = lane&15]
 }
 
-__global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) {
+__global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) { BACKEND_PRIO();
     __shared__ double red[BA_NW];
     __shared__ BAState st;
     __shared__ CamRot crot[32];
@@ -853,7 +853,7 @@ __device__ inline void bam_eval0_role(const BAArgs& A, BAGState* __restrict__ st
 
 // blocks [0, eval_blocks): E0; the remaining blocks clear Yt | [Wt | g] (adjacent; columns of cameras that do not see a point are
 // never written by the point kernel) — the clear rides along instead of being a launch of its own
-__global__ __launch_bounds__(BM_T) void k_bam_eval0(BAArgs A, BAGState* st_out, int* chol_flags, double* part_cost, int eval_blocks) {
+__global__ __launch_bounds__(BM_T) void k_bam_eval0(BAArgs A, BAGState* st_out, int* chol_flags, double* part_cost, int eval_blocks) { BACKEND_PRIO();
     if ((int)blockIdx.x < eval_blocks) { bam_eval0_role(A, st_out, chol_flags, part_cost, blockIdx.x, eval_blocks); return; }
     const size_t n2 = (size_t)A.krows * A.ldw;   // doubles in Yt + Wt = 2 * n2, a multiple of 2
     double2* z = (double2*)A.Yd;
@@ -1102,7 +1102,7 @@ __device__ inline void bam_campoint_role(const BAArgs& A, const BAGState* __rest
 }
 __global__ __launch_bounds__(BM_T) void k_bam_campoint(BAArgs A, const BAGState* st_in, BAGState* st_out, int decide, const double* part4,
                                                        int nbp, int* chol_flag, int cam_blocks, double* Ublk, double* rhsblk,
-                                                       double* part_gmax) {
+                                                       double* part_gmax) { BACKEND_PRIO();
     __shared__ double swork[BM_WORK];
     bam_campoint_role(A, st_in, st_out, decide != 0, part4, nbp, chol_flag, cam_blocks, Ublk, rhsblk, part_gmax, blockIdx.x, swork);
 }
@@ -1155,7 +1155,7 @@ __device__ inline void bam_gemm_role(const BAArgs& A, const BAGState* st, int bi
     }
 }
 
-__global__ __launch_bounds__(64 * BG_W) void k_bam_gemm(BAArgs A, const BAGState* st) {
+__global__ __launch_bounds__(64 * BG_W) void k_bam_gemm(BAArgs A, const BAGState* st) { BACKEND_PRIO();
     __shared__ double swork[BG_W * 4 * 64];
     bam_gemm_role(A, st, blockIdx.x, swork);
 }
@@ -1378,7 +1378,7 @@ __device__ inline void bam_solve_role(const BAArgs& A, BAGState* st, const int* 
 
 __global__ __launch_bounds__(BM_T) void k_bam_solve(BAArgs A, BAGState* st, const int* chol_flag, const double* part_cost, int nbo,
                                                     const double* part_gmax, int nbp, const double* Ublk, const double* rhsblk,
-                                                    double* candrot) {
+                                                    double* candrot) { BACKEND_PRIO();
     bam_solve_role(A, st, chol_flag, part_cost, nbo, part_gmax, nbp, Ublk, rhsblk, candrot);
 }
 
@@ -1502,7 +1502,7 @@ __device__ inline void bam_backsub_role(const BAArgs& A, const BAGState* st, con
 #undef BSTAMP
 }
 
-__global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* st, const double* candrot, double* tmp3, double* part4) {
+__global__ __launch_bounds__(BM_T) void k_bam_backsub(BAArgs A, const BAGState* st, const double* candrot, double* tmp3, double* part4) { BACKEND_PRIO();
     bam_backsub_role(A, st, candrot, tmp3, part4, blockIdx.x);
 }
 
@@ -1532,7 +1532,7 @@ __device__ inline void bam_finish_role(const BAArgs& A, const BAGState* __restri
     }
 }
 
-__global__ __launch_bounds__(BM_T) void k_bam_finish(BAArgs A, const BAGState* st_in, const double* part4, int nbp) {
+__global__ __launch_bounds__(BM_T) void k_bam_finish(BAArgs A, const BAGState* st_in, const double* part4, int nbp) { BACKEND_PRIO();
     bam_finish_role(A, st_in, part4, nbp);
 }
 
@@ -1592,7 +1592,7 @@ void ba_fill_prob(BAProb& P, const BAArgs& A, void* d_state, double* d_part) {
     P.clear_blocks = (int)std::min<size_t>(64, ((size_t)A.krows * A.ldw + 4 * BM_T - 1) / (4 * BM_T));
     P.tiles = A.tiles_r * A.tiles_c;
 }
-__global__ __launch_bounds__(BM_T) void k_bamB_eval0(const BAProb* __restrict__ probs) {
+__global__ __launch_bounds__(BM_T) void k_bamB_eval0(const BAProb* __restrict__ probs) { BACKEND_PRIO();
     const BAProb& P = probs[blockIdx.y];
     const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     const int bx = blockIdx.x;
@@ -1604,7 +1604,7 @@ __global__ __launch_bounds__(BM_T) void k_bamB_eval0(const BAProb* __restrict__ 
     for (size_t i = (size_t)zb * BM_T + threadIdx.x; i < n2; i += (size_t)nzb * BM_T) z[i] = double2{0.0, 0.0};
 }
 // part: 0 = cameras only, 1 = points only (first iteration: the point role needs the camera scales), 2 = both with the decision
-__global__ __launch_bounds__(BM_T) void k_bamB_campoint(const BAProb* __restrict__ probs, int it, int part) {
+__global__ __launch_bounds__(BM_T) void k_bamB_campoint(const BAProb* __restrict__ probs, int it, int part) { BACKEND_PRIO();
     __shared__ double swork[BM_WORK];
     const BAProb& P = probs[blockIdx.y];
     const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
@@ -1616,25 +1616,25 @@ __global__ __launch_bounds__(BM_T) void k_bamB_campoint(const BAProb* __restrict
     else if (part == 1) { if (bx >= P.nbp) return; bam_campoint_role(A, sc, sc, false, P.part4, P.nbp, cf, 0, P.Ublk, P.rhsblk, P.part_gmax, bx, swork); }
     else { if (bx >= A.nc + P.nbp) return; bam_campoint_role(A, sin, sc, true, P.part4, P.nbp, cf, A.nc, P.Ublk, P.rhsblk, P.part_gmax, bx, swork); }
 }
-__global__ __launch_bounds__(64 * BG_W) void k_bamB_gemm(const BAProb* __restrict__ probs, int it) {
+__global__ __launch_bounds__(64 * BG_W) void k_bamB_gemm(const BAProb* __restrict__ probs, int it) { BACKEND_PRIO();
     __shared__ double swork[BG_W * 4 * 64];
     const BAProb& P = probs[blockIdx.y];
     if ((int)blockIdx.x >= P.tiles * BG_H) return;
     const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     bam_gemm_role(A, (const BAGState*)P.st2[(it + 1) & 1], blockIdx.x, swork);
 }
-__global__ __launch_bounds__(BM_T) void k_bamB_solve(const BAProb* __restrict__ probs, int it) {
+__global__ __launch_bounds__(BM_T) void k_bamB_solve(const BAProb* __restrict__ probs, int it) { BACKEND_PRIO();
     const BAProb& P = probs[blockIdx.x];
     const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     bam_solve_role(A, (BAGState*)P.st2[(it + 1) & 1], P.chol_flags + it, P.part_cost, P.nbo, P.part_gmax, P.nbp, P.Ublk, P.rhsblk, P.candrot);
 }
-__global__ __launch_bounds__(BM_T) void k_bamB_backsub(const BAProb* __restrict__ probs, int it) {
+__global__ __launch_bounds__(BM_T) void k_bamB_backsub(const BAProb* __restrict__ probs, int it) { BACKEND_PRIO();
     const BAProb& P = probs[blockIdx.y];
     if ((int)blockIdx.x >= P.nbp) return;
     const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     bam_backsub_role(A, (const BAGState*)P.st2[(it + 1) & 1], P.candrot, P.tmp3, P.part4, blockIdx.x);
 }
-__global__ __launch_bounds__(BM_T) void k_bamB_finish(const BAProb* __restrict__ probs, int max_it) {
+__global__ __launch_bounds__(BM_T) void k_bamB_finish(const BAProb* __restrict__ probs, int max_it) { BACKEND_PRIO();
     const BAProb& P = probs[blockIdx.x];
     const BAArgs A = P.A;   // by value (uniform address -> scalar loads once); a reference would be re-read after every store: 29 -> 57 us for k_bamB_campoint
     bam_finish_role(A, (const BAGState*)P.st2[max_it & 1], P.part4, P.nbp);

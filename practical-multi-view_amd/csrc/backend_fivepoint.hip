@@ -230,7 +230,7 @@ __device__ int fp_essentials(const double* q1, const double* q2, double* E_out) 
 }  // namespace
 
 // samples: n_hyp x 5 correspondence indices; q1, q2: n normalised points; models: n_hyp x 90 doubles; n_models: n_hyp ints
-__global__ __launch_bounds__(64) void k_fivepoint_hyp(const FivePointProblem* __restrict__ probs) {
+__global__ __launch_bounds__(64) void k_fivepoint_hyp(const FivePointProblem* __restrict__ probs) { BACKEND_PRIO();
     const FivePointProblem P = probs[blockIdx.y];
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= P.n_hyp) return;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const FivePointProblem* __
 }
 
 // EMEstimatorCallback::computeError (Sampson distance stored as float32) + inlier count per (hypothesis, model): one wavefront each
-__global__ __launch_bounds__(64) void k_fivepoint_score(const FivePointProblem* __restrict__ probs) {
+__global__ __launch_bounds__(64) void k_fivepoint_score(const FivePointProblem* __restrict__ probs) { BACKEND_PRIO();
     const FivePointProblem P = probs[blockIdx.z];
     const int h = blockIdx.y, mi = blockIdx.x;
     if (h >= P.n_hyp || mi >= P.n_models_d[h]) return;

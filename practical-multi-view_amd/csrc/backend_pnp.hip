@@ -740,7 +740,7 @@ __device__ __forceinline__ void pnp_select_refit_body(const float* __restrict__ 
 __global__ __launch_bounds__(64) void k_pnp_hyp(const float* __restrict__ obj, const float* __restrict__ img,
                                                 const int* __restrict__ samples, const double* __restrict__ K,
                                                 double* __restrict__ models, int m, float thr, uint8_t* __restrict__ masks,
-                                                int* __restrict__ counts, unsigned long long* stamps) {
+                                                int* __restrict__ counts, unsigned long long* stamps) { BACKEND_PRIO();
     pnp_hyp_body<false>(obj, img, samples, K, models, m, thr, masks, counts, stamps, blockIdx.x);
 }
 __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restrict__ obj, const float* __restrict__ img, int m,
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
                                                            const uint8_t* __restrict__ masks, const int* __restrict__ counts,
                                                            int n_hyp, double confidence, double* __restrict__ rt_out,
                                                            int* __restrict__ inliers, int* __restrict__ info, char* __restrict__ host_out,
-                                                           unsigned long long* stamps, unsigned done_seq) {
+                                                           unsigned long long* stamps, unsigned done_seq) { BACKEND_PRIO();
     pnp_select_refit_body(obj, img, m, K, models, masks, counts, n_hyp, confidence, rt_out, inliers, info, host_out, stamps, done_seq);
 }
 // batched forms: blockIdx.y = problem (several sequences' PnP calls in one launch), same per-problem arithmetic
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(RF_T) void k_pnp_select_refit(const float* __restri
 // count, and the wavefront returns at once. (cv::solvePnPRansac on typical inlier ratios stops after ~10-20 of its 100 iterations;
 // the single-sequence launch evaluates all 100 side by side because it is bound by one hypothesis' latency, the batched launch
 // is bound by how many wavefronts the chip can hold.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pnp_hyp_batch(const PnPProblem* __restrict__ probs, int h0, int replay) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pnp_hyp_batch(const PnPProblem* __restrict__ probs, int h0, int replay) { BACKEND_PRIO();
     const PnPProblem p = probs[blockIdx.y];
     const int h = h0 + (int)blockIdx.x;
     if (h >= p.n_hyp) return;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     pnp_hyp_body<true>(p.obj, p.img, p.samples, p.K, p.models, p.m, p.thr, p.masks, p.counts, nullptr, h);
 }
-__global__ __launch_bounds__(RF_T) void k_pnp_select_refit_batch(const PnPProblem* __restrict__ probs) {
+__global__ __launch_bounds__(RF_T) void k_pnp_select_refit_batch(const PnPProblem* __restrict__ probs) { BACKEND_PRIO();
     const PnPProblem p = probs[blockIdx.x];
     pnp_select_refit_body(p.obj, p.img, p.m, p.K, p.models, p.masks, p.counts, p.n_hyp, p.confidence, p.rt_out, p.inliers, p.info, p.host_out, nullptr, 0u);
 }

@@ -52,11 +52,11 @@ __device__ __forceinline__ void tri_dlt_body(const double* __restrict__ P1x4, co
 
 __global__ __launch_bounds__(64) void k_tri_dlt(const double* __restrict__ P1x4, const double* __restrict__ q1,
                                                 const double* __restrict__ q2, const uint8_t* __restrict__ mask_in, int n,
-                                                double* __restrict__ Q, uint8_t* __restrict__ mask) {
+                                                double* __restrict__ Q, uint8_t* __restrict__ mask) { BACKEND_PRIO();
     tri_dlt_body(P1x4, q1, q2, mask_in, n, Q, mask, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
 }
 // batched: blockIdx.z = problem
-__global__ __launch_bounds__(64) void k_tri_dlt_batch(const DltProblem* __restrict__ probs) {
+__global__ __launch_bounds__(64) void k_tri_dlt_batch(const DltProblem* __restrict__ probs) { BACKEND_PRIO();
     const DltProblem p = probs[blockIdx.z];
     tri_dlt_body(p.P1x4, p.q1, p.q2, p.mask_in, p.n, p.Q, p.mask, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
 }

@@ -6,6 +6,9 @@ namespace pmv {
 struct BatchEngine;
 int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out);   // creates (or grows) the context's engine for B concurrent sequences
 void batch_engine_destroy(pmv_ctx* ctx);
+// pyramids of the run's sequences built in the background while the sequences already track (see BatchEngine::slot_round)
+int engine_build_begin(BatchEngine* E, int B, const int* first_slot, const int* n_frames, const int* build);
+int engine_build_end(BatchEngine* E);
 // per combiner (LK, detectors, PnP, BA, DLT): counts10 = {launch rounds, requests} x 5; times15 (may be null) = seconds spent
 // {CPU time of the combiner thread, wall time processing batches, of that waiting for the GPU} x 5
 void batch_engine_stats(BatchEngine* E, long long* counts10, double* times15);

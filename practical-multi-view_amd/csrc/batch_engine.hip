@@ -97,11 +97,11 @@ struct Combiner {
     double ema_wait_us = 0;            // smoothed duration of the wait of a round (how long to sleep before the first look)
 };
 
-__global__ void k_signal(unsigned* done, unsigned seq) { __threadfence_system(); __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ void k_signal(unsigned* done, unsigned seq) { BACKEND_PRIO(); __threadfence_system(); __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // one input block to pull from mapped pinned host memory into HBM (16-byte granules; both buffers have >= 16 B of slack)
 struct StageJob { const char* src; char* dst; unsigned bytes, pad; };
-__global__ __launch_bounds__(256) void k_stage_in(const StageJob* __restrict__ jobs) {
+__global__ __launch_bounds__(256) void k_stage_in(const StageJob* __restrict__ jobs) { BACKEND_PRIO();
     const StageJob j = jobs[blockIdx.y];
     const unsigned n16 = (j.bytes + 15u) >> 4;
     const uint4* __restrict__ src = (const uint4*)j.src;
@@ -117,12 +117,27 @@ struct BatchEngine {
     int linger_us = 0;
     int wait_mode = 3;   // 0 spin (hipStreamSynchronize), 1 query + yield, 2 blocking event, 3 completion word + timed sleeps
     std::vector<BackendBuffers*> slots;   // one back-end workspace set per concurrent sequence
-    int lanes = 1;   // measured: 2 and 3 combiners per class cost more host CPU (smaller batches) than they win in latency: 25.7k -> 23.3k -> 19.5k frames/s at B = 64
+    // combiners (thread + stream) per class. Round 2, host-bound: 2 and 3 per class cost more host CPU (smaller batches) than they won in
+    // latency (25.7k -> 23.3k -> 19.5k frames/s at B = 64). Round 3, with the track tables the host has headroom and the LK class is the one
+    // that is busy all the time - a launch ends with its slowest track, so a single LK stream idles most SIMDs during every tail: PMV_BATCH_LANES
+    // sets all classes, PMV_BATCH_LANES_LK / _PNP / _BA one class.
+    int lanes[R_COUNT] = {1, 1, 1, 1, 1, 1};
     Queue queue[R_COUNT];
     Combiner comb[R_COUNT][MAX_LANES];
     size_t cap_tracks = 0;
     bool exclusive = false;
     std::mutex exclusive_mu;
+    // Pyramids of a batched run are built WHILE the sequences already track (engine_build_begin): round r = frames [r * BUILD_CHUNK,
+    // (r + 1) * BUILD_CHUNK) of every sequence, enqueued round by round on the context's front-end stream with an event after each.
+    // A front-end launch that touches slot s first makes its stream wait for the event of slot_round[s] (a GPU-side dependency; the host
+    // only waits until that round has been ENQUEUED, which is milliseconds after the start). Before this the 1.1 ms of pyramid kernels
+    // per sequence ran back to back in front of everything: 141 ms of a 3 s pass at B = 128 with nothing else on the GPU.
+    static constexpr int BUILD_CHUNK = 32;
+    std::vector<int> slot_round;            // per frame slot: its build round, -1 = nothing to wait for
+    std::vector<hipEvent_t> build_ev;       // per round
+    std::atomic<int> build_enqueued{0};     // rounds whose launches and event are in the stream
+    std::atomic<int> build_error{0};
+    std::thread build_thread;
 };
 
 namespace {
@@ -178,6 +193,16 @@ hipError_t wait_stream(BatchEngine* E, Combiner& C) {
     return hipSuccess;
 }
 
+// make stream `s` wait for the pyramid build round `need` (see BatchEngine::slot_round)
+hipError_t wait_built(BatchEngine* E, hipStream_t s, int need) {
+    if (need < 0 || need >= (int)E->build_ev.size()) return hipSuccess;
+    while (E->build_enqueued.load(std::memory_order_acquire) <= need) {
+        if (E->build_error.load()) return hipErrorUnknown;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    return hipStreamWaitEvent(s, E->build_ev[(size_t)need], 0);
+}
+
 // ---- LK -------------------------------------------------------------------------------------------------------------------------
 void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     pmv_ctx* ctx = E->ctx;
@@ -185,20 +210,24 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     std::vector<LKReq*> lk;
     for (Req* r : batch) lk.push_back((LKReq*)r);
     // ---- LK: one launch for the tracks of every requesting sequence
-    int total_tracks = 0, total_blocks = 0;
+    int total_tracks = 0, total_blocks = 0, need_round = -1;
     PyrLayout L{};
     bool have_L = false;
+    // (a slot whose pyramid the background build has not reached yet is "staged": n_levels < 0; the launch below waits for its round)
     for (LKReq* r : lk) {
-        const PyrLayout& a = ctx->slot_layout[r->prev_slot];
+        PyrLayout a = ctx->slot_layout[r->prev_slot];
         const PyrLayout& b2 = ctx->slot_layout[r->next_slot];
-        if (a.n_levels <= 0 || b2.n_levels <= 0 || a.w[0] != b2.w[0] || a.h[0] != b2.h[0]) { r->rc = PMV_ERR_INVALID; snprintf(r->err, sizeof(r->err), "batch LK: slot has no pyramid / sizes differ"); continue; }
+        if (a.n_levels < 0) a.n_levels = -a.n_levels;
+        if (a.n_levels == 0 || b2.n_levels == 0 || a.w[0] != b2.w[0] || a.h[0] != b2.h[0]) { r->rc = PMV_ERR_INVALID; snprintf(r->err, sizeof(r->err), "batch LK: slot has no pyramid / sizes differ"); continue; }
         if (!have_L) { L = a; have_L = true; }
         else if (a.w[0] != L.w[0] || a.h[0] != L.h[0]) { r->rc = PMV_ERR_INVALID; snprintf(r->err, sizeof(r->err), "batch LK: all sequences of a batch must share the frame size"); continue; }
         r->base = total_tracks;
         total_tracks += r->n;
         total_blocks += (int)r->order.size();
+        if (!E->slot_round.empty()) need_round = std::max(need_round, std::max(E->slot_round[(size_t)r->prev_slot], E->slot_round[(size_t)r->next_slot]));
     }
     if (total_tracks > 0) {
+        EK(wait_built(E, s, need_round));
         if ((size_t)total_tracks > E->cap_tracks) { fail_all(batch, PMV_ERR_CAPACITY, "more tracks than B * max_tracks", hipSuccess); return; }
         const size_t off_blocks = (sizeof(LKSeq) * lk.size() + 63) & ~(size_t)63;
         const size_t off_xy = (off_blocks + sizeof(int2) * (size_t)total_blocks + 63) & ~(size_t)63;
@@ -243,7 +272,8 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     struct Group { int kind, max_per_cell, unlimited; double quality, min_dist; PyrLayout L; std::vector<DetReq*> reqs; int n_cells = 0; size_t out_off = 0; };
     std::vector<Group> groups;
     for (DetReq* r : det) {
-        const PyrLayout& Lr = ctx->slot_layout[r->slot];
+        PyrLayout Lr = ctx->slot_layout[r->slot];
+        if (Lr.n_levels < 0) Lr.n_levels = -Lr.n_levels;   // staged, its build round is awaited below
         Group* g = nullptr;
         for (Group& x : groups)
             if (x.kind == r->kind && x.max_per_cell == r->max_per_cell && x.unlimited == r->unlimited && x.quality == r->quality && x.min_dist == r->min_dist &&
@@ -268,6 +298,11 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
                     d[0] = r->cells[4 * i]; d[1] = r->cells[4 * i + 1]; d[2] = r->cells[4 * i + 2]; d[3] = r->cells[4 * i + 3]; d[4] = r->slot; d[5] = d[6] = d[7] = 0;
                 }
         EK(hipMemsetAsync(C.d_flags, 0, 16, s));
+        {
+            int need_round = -1;
+            if (!E->slot_round.empty()) for (DetReq* r : det) need_round = std::max(need_round, E->slot_round[(size_t)r->slot]);
+            EK(wait_built(E, s, need_round));
+        }
         size_t c0 = 0;
         char* hd = (char*)C.h_det.p;
         char* dd = C.h_det.dev;
@@ -491,6 +526,8 @@ void batch_engine_destroy(pmv_ctx* ctx) {
             if (C.h_status) (void)hipHostFree(C.h_status);
             if (C.d_flags) (void)hipFree(C.d_flags);
         }
+    if (E->build_thread.joinable()) E->build_thread.join();
+    for (hipEvent_t ev : E->build_ev) (void)hipEventDestroy(ev);
     for (BackendBuffers* b : E->slots) backend_free(b);
     delete E;
     ctx->engine = nullptr;
@@ -513,10 +550,14 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
     }
     E->cap_tracks = (size_t)B * ctx->max_tracks;
     if (const char* e = getenv("PMV_BATCH_EXCLUSIVE")) E->exclusive = atoi(e) != 0;
-    if (const char* e = getenv("PMV_BATCH_LANES")) E->lanes = std::max(1, std::min(MAX_LANES, atoi(e)));
+    E->lanes[R_LK] = 2;   // (measured, B = 128: see DESIGN.md §5)
+    if (const char* e = getenv("PMV_BATCH_LANES")) for (int& l : E->lanes) l = std::max(1, std::min(MAX_LANES, atoi(e)));
+    if (const char* e = getenv("PMV_BATCH_LANES_LK")) E->lanes[R_LK] = std::max(1, std::min(MAX_LANES, atoi(e)));
+    if (const char* e = getenv("PMV_BATCH_LANES_PNP")) E->lanes[R_PNP] = std::max(1, std::min(MAX_LANES, atoi(e)));
+    if (const char* e = getenv("PMV_BATCH_LANES_BA")) E->lanes[R_BA] = std::max(1, std::min(MAX_LANES, atoi(e)));
     if (const char* e = getenv("PMV_BATCH_WAIT")) E->wait_mode = !strcmp(e, "spin") ? 0 : !strcmp(e, "yield") ? 1 : !strcmp(e, "block") ? 2 : 3;
     for (int r = 0; r < R_COUNT; r++)
-        for (int l = 0; l < E->lanes; l++) {
+        for (int l = 0; l < E->lanes[r]; l++) {
             Combiner& C = E->comb[r][l];
             // the back-end classes are chains of small launches (a BA solve: 23 of them): they get the higher stream priority so their
             // workgroups are not queued behind the thousands of LK / detector waves of the front-end classes (PMV_BATCH_PRIO=0: all equal)
@@ -542,9 +583,51 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
             if (r == R_DET) CKC(hipMalloc(&C.d_flags, 16));
         }
     for (int r = 0; r < R_COUNT; r++)
-        for (int l = 0; l < E->lanes; l++) E->comb[r][l].th = std::thread(combiner_loop, E, r, l);
+        for (int l = 0; l < E->lanes[r]; l++) E->comb[r][l].th = std::thread(combiner_loop, E, r, l);
     *out = E;
     return PMV_OK;
+}
+
+// Start building the pyramids of B sequences (frames first_slot[b] .. + n_frames[b] - 1, only where build[b] != 0) in the background;
+// engine_build_end() joins. The slots must have been staged with one frame geometry.
+int engine_build_begin(BatchEngine* E, int B, const int* first_slot, const int* n_frames, const int* build) {
+    pmv_ctx* ctx = E->ctx;
+    CKC(hipSetDevice(ctx->device));
+    E->slot_round.assign((size_t)ctx->n_slots, -1);
+    int max_n = 0;
+    for (int b = 0; b < B; b++) if (build[b]) {
+        max_n = std::max(max_n, n_frames[b]);
+        for (int f = 0; f < n_frames[b]; f++) E->slot_round[(size_t)(first_slot[b] + f)] = f / BatchEngine::BUILD_CHUNK;
+    }
+    const int rounds = (max_n + BatchEngine::BUILD_CHUNK - 1) / BatchEngine::BUILD_CHUNK;
+    while ((int)E->build_ev.size() < rounds) {
+        hipEvent_t ev;
+        CKC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        E->build_ev.push_back(ev);
+    }
+    E->build_enqueued.store(0);
+    E->build_error.store(0);
+    if (rounds == 0) return PMV_OK;
+    std::vector<int> fs(first_slot, first_slot + B), nf(n_frames, n_frames + B), bd(build, build + B);
+    E->build_thread = std::thread([E, ctx, B, rounds, fs, nf, bd] {
+        (void)hipSetDevice(ctx->device);
+        tl_prof = &ctx->prof;
+        for (int r = 0; r < rounds; r++) {
+            for (int b = 0; b < B; b++) {
+                const int f0 = r * BatchEngine::BUILD_CHUNK, n = std::min(BatchEngine::BUILD_CHUNK, nf[(size_t)b] - f0);
+                if (!bd[(size_t)b] || n <= 0) continue;
+                if (pmv_frames_build_on(ctx, ctx->s_front, fs[(size_t)b] + f0, n) != PMV_OK) { E->build_error.store(1); return; }
+            }
+            if (hipEventRecord(E->build_ev[(size_t)r], ctx->s_front) != hipSuccess) { E->build_error.store(1); return; }
+            E->build_enqueued.store(r + 1, std::memory_order_release);
+        }
+    });
+    return PMV_OK;
+}
+int engine_build_end(BatchEngine* E) {
+    if (E->build_thread.joinable()) E->build_thread.join();
+    E->slot_round.clear();
+    return E->build_error.load() ? PMV_ERR_HIP : PMV_OK;
 }
 
 void batch_engine_stats(BatchEngine* E, long long* counts10, double* times15) {
@@ -552,7 +635,7 @@ void batch_engine_stats(BatchEngine* E, long long* counts10, double* times15) {
 
         counts10[2 * r] = counts10[2 * r + 1] = 0;
         if (times15) times15[3 * r] = times15[3 * r + 1] = times15[3 * r + 2] = 0;
-        for (int l = 0; l < E->lanes; l++) {   // summed over the class's combiners
+        for (int l = 0; l < E->lanes[r]; l++) {   // summed over the class's combiners
             const Combiner& C = E->comb[r][l];
             counts10[2 * r] += C.batches; counts10[2 * r + 1] += C.requests;
             if (times15) { times15[3 * r] += C.t_cpu; times15[3 * r + 1] += C.t_work; times15[3 * r + 2] += C.t_sync; }
@@ -591,7 +674,7 @@ int engine_detect(BatchEngine* E, int kind, int slot, const int* cells, int n_ce
     r.kind = kind; r.slot = slot; r.cells = cells; r.n_cells = n_cells; r.unlimited = max_per_cell <= 0;
     r.max_per_cell = r.unlimited ? MAX_PER_CELL : max_per_cell;
     REQ(r.max_per_cell <= MAX_PER_CELL, PMV_ERR_CAPACITY, "detect: max_per_cell=%d (max %d)", max_per_cell, MAX_PER_CELL);
-    REQ(slot >= 0 && slot < ctx->n_slots && ctx->slot_layout[slot].n_levels > 0, PMV_ERR_INVALID, "detect: slot %d has no frame", slot);
+    REQ(slot >= 0 && slot < ctx->n_slots && ctx->slot_layout[slot].n_levels != 0, PMV_ERR_INVALID, "detect: slot %d has no frame", slot);
     const PyrLayout& L = ctx->slot_layout[slot];
     for (int i = 0; i < n_cells; i++) {
         const int* c = cells + 4 * i;

@@ -44,8 +44,10 @@ PyrLayout pmv::make_layout(int w, int h) {
         if (lw <= LK_WIN || lh <= LK_WIN) break;
     }
     L.n_levels = n;
-    L.gray_off = off;
-    off += (uint32_t)((w * h + 255) & ~255);
+    // No separate copy of the gray frame: staging writes its rows into the interior of the padded level 0 and k_pad_level0 adds the
+    // REFLECT_101 frame around them in place (1.11 MB per 1241x376 slot instead of 1.58 MB: 192 sequences of the metric configuration
+    // fit the 288 GB instead of 128)
+    L.gray_off = L.off[0] + (uint32_t)PAD * (uint32_t)L.stride[0] + (uint32_t)PAD;
     L.slot_bytes = (off + 4095) & ~4095u;
     return L;
 }
@@ -85,6 +87,7 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     CK(hipStreamCreateWithFlags(&c->s_front, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&c->s_back, hipStreamNonBlocking));
     CK(hipMalloc(&c->d_slots, (size_t)c->cap.slot_bytes * n_slots));
+    CK(hipMalloc(&c->d_tight, (size_t)pmv_ctx::TIGHT_FRAMES * max_w * max_h + 256));
     const size_t nt = (size_t)max_tracks;
     CK(hipMalloc(&c->d_prev_xy, nt * 12 + 64));   // track coordinates followed by the block -> track order
     CK(hipMalloc(&c->d_out_xy, nt * 8));
@@ -117,7 +120,7 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     int rc = backend_create(c);
     if (rc != PMV_OK) { snprintf(g_create_err, sizeof(g_create_err), "%s", c->err); pmv_ctx_destroy(c); return rc; }
     {   // every buffer a kernel may touch exists (a missed allocation must fail here, not as a GPU fault later)
-        const void* must[] = {c->dm_out_xy, c->dm_status, c->dm_err, c->d_slots, c->d_prev_xy, c->d_out_xy, c->d_status, c->d_err, c->h_prev_xy, c->h_out_xy, c->h_status, c->h_err,
+        const void* must[] = {c->dm_out_xy, c->dm_status, c->dm_err, c->d_slots, c->d_tight, c->d_prev_xy, c->d_out_xy, c->d_status, c->d_err, c->h_prev_xy, c->h_out_xy, c->h_status, c->h_err,
                               c->d_cells, c->d_eig, c->d_cellmax, c->d_det_xy, c->d_det_score, c->d_det_count, c->d_flags, c->h_det_xy,
                               c->h_det_score, c->h_det_count};
         for (const void* p : must)
@@ -143,6 +146,7 @@ void pmv_ctx_destroy(pmv_ctx* c) {
     if (c->h_knn) hipHostFree(c->h_knn);
     hipFree(c->d_slots); hipFree(c->d_prev_xy); hipFree(c->d_out_xy); hipFree(c->d_status); hipFree(c->d_err);
     hipHostFree(c->h_prev_xy); hipHostFree(c->h_out_xy); hipHostFree(c->h_status); hipHostFree(c->h_err);
+    hipFree(c->d_tight);
     hipFree(c->d_cells); hipFree(c->d_eig); hipFree(c->d_cellmax); hipFree(c->d_det_xy); hipFree(c->d_det_score);
     hipFree(c->d_det_count); hipFree(c->d_flags); hipFree(c->d_spill);
     hipHostFree(c->h_det_xy); hipHostFree(c->h_det_score); hipHostFree(c->h_det_count); hipHostFree(c->h_cells);
@@ -162,12 +166,12 @@ int pmv_sync(pmv_ctx* ctx) {
 }
 
 }  // extern "C"
-int pmv::build_levels_on(pmv_ctx* ctx, hipStream_t stream, int first_slot, int n, const PyrLayout& L) {
-    CKC(launch_pad_level0(stream, ctx->d_slots, L, first_slot, n));
+// tight != nullptr: level 0 comes from n tight gray frames at `tight` (device) instead of from the levels' own interior
+int pmv::build_levels_on(pmv_ctx* ctx, hipStream_t stream, int first_slot, int n, const PyrLayout& L, const uint8_t* tight) {
+    CKC(launch_pad_level0(stream, ctx->d_slots, L, first_slot, n, tight));
     for (int l = 1; l < L.n_levels; l++) CKC(launch_pyrdown(stream, ctx->d_slots, L, l, first_slot, n));
     return PMV_OK;
 }
-static int build_levels(pmv_ctx* ctx, int first_slot, int n, const PyrLayout& L) { return build_levels_on(ctx, ctx->s_front, first_slot, n, L); }
 
 // NOTE: slots are addressed with the CAPACITY slot size (ctx->cap.slot_bytes); a frame smaller than max_w x max_h
 // uses its own level geometry inside the slot but the same slot pitch.
@@ -184,9 +188,13 @@ int pmv_frames_stage(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, i
     REQ(w >= 40 && h >= 40 && w <= ctx->max_w && h <= ctx->max_h, PMV_ERR_CAPACITY, "pmv_frames_stage: frame %dx%d outside capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
     CKC(hipSetDevice(ctx->device));
     PyrLayout L = layout_for(ctx, w, h);
-    for (int i = 0; i < n; i++)
-        CKC(hipMemcpyAsync(ctx->d_slots + (size_t)(first_slot + i) * L.slot_bytes + L.gray_off, gray + (size_t)i * w * h,
-                           (size_t)w * h, hipMemcpyHostToDevice, ctx->s_front));
+    // contiguous copies into the landing area, then level 0 (interior + REFLECT_101 frame) written by k_pad_level0 from there
+    const size_t fb = (size_t)w * h;
+    for (int i0 = 0; i0 < n; i0 += pmv_ctx::TIGHT_FRAMES) {
+        const int nb = std::min((int)pmv_ctx::TIGHT_FRAMES, n - i0);
+        CKC(hipMemcpyAsync(ctx->d_tight, gray + (size_t)i0 * fb, (size_t)nb * fb, hipMemcpyHostToDevice, ctx->s_front));
+        CKC(launch_pad_level0(ctx->s_front, ctx->d_slots, L, first_slot + i0, nb, ctx->d_tight));
+    }
     CKC(hipStreamSynchronize(ctx->s_front));
     for (int i = 0; i < n; i++) { ctx->slot_layout[first_slot + i] = L; ctx->slot_layout[first_slot + i].n_levels = -L.n_levels; }
     return PMV_OK;
@@ -195,6 +203,10 @@ int pmv_frames_stage(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, i
 int pmv_frames_build(pmv_ctx* ctx, int first_slot, int n) {
     REQ(ctx, PMV_ERR_INVALID, "null ctx");
     tl_prof = &ctx->prof;
+    return pmv::pmv_frames_build_on(ctx, ctx->s_front, first_slot, n);
+}
+}  // extern "C"
+int pmv::pmv_frames_build_on(pmv_ctx* ctx, hipStream_t stream, int first_slot, int n) {
     REQ(first_slot >= 0 && n >= 1 && first_slot + n <= ctx->n_slots, PMV_ERR_CAPACITY, "pmv_frames_build: slot range");
     CKC(hipSetDevice(ctx->device));
     // consecutive slots with identical geometry are built in one batched launch per level
@@ -205,13 +217,14 @@ int pmv_frames_build(pmv_ctx* ctx, int first_slot, int n) {
         int j = i + 1;
         while (j < n && ctx->slot_layout[first_slot + j].w[0] == L.w[0] && ctx->slot_layout[first_slot + j].h[0] == L.h[0]) j++;
         if (L.n_levels < 0) L.n_levels = -L.n_levels;
-        int rc = build_levels(ctx, first_slot + i, j - i, L);
+        int rc = build_levels_on(ctx, stream, first_slot + i, j - i, L);
         if (rc) return rc;
         for (int k = i; k < j; k++) ctx->slot_layout[first_slot + k].n_levels = L.n_levels;
         i = j;
     }
     return PMV_OK;
 }
+extern "C" {
 
 int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, int stride) {
     REQ(ctx && gray, PMV_ERR_INVALID, "pmv_frame_upload: null argument");
@@ -220,8 +233,8 @@ int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, 
     tl_prof = &ctx->prof;
     CKC(hipSetDevice(ctx->device));
     PyrLayout L = layout_for(ctx, w, h);
-    CKC(hipMemcpy2DAsync(ctx->d_slots + (size_t)slot * L.slot_bytes + L.gray_off, w, gray, stride, w, h, hipMemcpyHostToDevice, ctx->s_front));
-    int rc = build_levels(ctx, slot, 1, L);
+    CKC(hipMemcpy2DAsync(ctx->d_tight, (size_t)w, gray, stride, w, h, hipMemcpyHostToDevice, ctx->s_front));
+    int rc = build_levels_on(ctx, ctx->s_front, slot, 1, L, ctx->d_tight);
     if (rc) return rc;
     CKC(hipStreamSynchronize(ctx->s_front));   // the host buffer may be reused by the caller
     ctx->slot_layout[slot] = L;

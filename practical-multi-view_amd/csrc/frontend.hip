@@ -74,11 +74,14 @@ __device__ inline void write_padded_row(const uint8_t* lrow, int lead, int w, ui
     }
 }
 
-// level 0: tight gray frame -> padded REFLECT_101 buffer. The source row (tight, so generally unaligned) is fetched as the aligned
-// dwords that cover it.
+// level 0: the gray frame sits in the interior of its padded buffer (staged there row by row); this kernel adds the REFLECT_101 frame
+// IN PLACE: every padded row is rebuilt from the interior row it mirrors (an interior row from itself: same bytes; a border row from
+// another row's interior, which no block changes).
 constexpr int PAD0_T = 128, PAD0_R = 4;   // rows per workgroup: their loads are in flight together
 __host__ __device__ inline int pad0_row_lds(int w) { return ((w + 3 + 24 + 3) / 4) * 4; }
-__global__ __launch_bounds__(PAD0_T) void k_pad_level0(uint8_t* slots, PyrLayout L, int first_slot) {
+// `tight` != nullptr: the frames come from a buffer of tight gray frames (frame z at tight + z * w * h: staging / upload / ingest; rows
+// generally unaligned, fetched as the aligned dwords that cover them) instead of from the level's own interior.
+__global__ __launch_bounds__(PAD0_T) void k_pad_level0(uint8_t* slots, PyrLayout L, int first_slot, const uint8_t* __restrict__ tight) {
     extern __shared__ __attribute__((aligned(16))) uint8_t srow_all[];   // PAD0_R x row_lds bytes
     uint8_t* slot = slots + (size_t)(first_slot + blockIdx.z) * L.slot_bytes;
     const int w = L.w[0], h = L.h[0], stride = L.stride[0];
@@ -90,11 +93,18 @@ __global__ __launch_bounds__(PAD0_T) void k_pad_level0(uint8_t* slots, PyrLayout
     for (int r = 0; r < PAD0_R; r++) {
         const int py = py0 + r < ph ? py0 + r : ph - 1;     // (rows past the end repeat the last one; they are not stored)
         const int sy = reflect101(py - PAD, h);
-        const unsigned b = (unsigned)sy * (unsigned)w;      // byte offset of the source row inside the gray block (gray_off % 64 == 0)
-        const unsigned a0 = b & ~3u;
-        lead[r] = b & 3u;
-        const uint32_t* src = (const uint32_t*)(slot + L.gray_off + a0);
-        const int nd = (int)((lead[r] + (unsigned)w + 3u) >> 2);   // dwords that contain a byte of the row: all inside the gray block
+        const uint32_t* src;
+        int nd;
+        if (tight) {
+            const size_t b = (size_t)blockIdx.z * (size_t)w * (size_t)h + (size_t)sy * (size_t)w;   // byte offset of the source row (the buffer is 256-byte aligned and has slack behind it)
+            lead[r] = (unsigned)(b & 3u);
+            src = (const uint32_t*)(tight + (b & ~(size_t)3));
+            nd = (int)((lead[r] + (unsigned)w + 3u) >> 2);
+        } else {
+            lead[r] = 0u;                                   // interior rows start 64-byte aligned (PAD and the stride are multiples of 64)
+            src = (const uint32_t*)(slot + L.gray_off + (size_t)sy * (size_t)stride);
+            nd = (w + 3) >> 2;                              // (the last dword may reach into the right border: inside the buffer)
+        }
         uint32_t* srow = (uint32_t*)(srow_all + r * row_lds);
         for (int d = threadIdx.x; d < nd; d += PAD0_T) srow[d] = src[d];
     }
@@ -178,12 +188,12 @@ __global__ __launch_bounds__(PYR_T) void k_pyrdown(uint8_t* slots, PyrLayout L, 
     }
 }
 
-hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n) {
+hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n, const uint8_t* tight) {
     if (!slots || n < 1 || first_slot < 0 || L.n_levels < 1) return hipErrorInvalidValue;
     dim3 grid(1, (L.h[0] + 2 * PAD + PAD0_R - 1) / PAD0_R, n);
     const size_t shm = (size_t)pad0_row_lds(L.w[0]) * PAD0_R;
     ProfScope ps(K_PAD0, s);
-    hipLaunchKernelGGL(k_pad_level0, grid, dim3(PAD0_T), shm, s, slots, L, first_slot);
+    hipLaunchKernelGGL(k_pad_level0, grid, dim3(PAD0_T), shm, s, slots, L, first_slot, tight);
     return hipGetLastError();
 }
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int ld, int first_slot, int n) {
@@ -385,7 +395,10 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
         __syncthreads();
         LSTAMP(2);
         // ---- this thread's PP window samples (I with 5 fractional bits, Ix, Iy) + exact A sums
-        int Iv[PP], Ix[PP], Iy[PP];
+        // Ix / Iy of two neighbouring pixels share a register as 16-bit halves (|derivative sample| <= 4080): the window sums then take one
+        // v_dot2_i32_i16 per pixel PAIR instead of a 24-bit multiply and an add per pixel - the same exact integers
+        int Iv[PP];
+        uint32_t IxP[PP / 2], IyP[PP / 2];
         int apart[3] = {0, 0, 0};
         {
             uint32_t ia[(PP + 1 + 3) / 4], ib[(PP + 1 + 3) / 4];
@@ -406,9 +419,13 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 Iv[k] = (1 << 8) - ((dot2_acc(pn, W1, dot2_acc(pc, W0, 1 << 8)) >> 9) << 9);
                 const int ixv = dot2_acc(xn, W1, dot2_acc(xc, W0, 1 << 13)) >> 14;
                 const int iyv = dot2_acc(yn, W1, dot2_acc(yc, W0, 1 << 13)) >> 14;
-                Ix[k] = ixv; Iy[k] = iyv;
-                // every factor fits 24 bits (derivatives 13): v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter
-                apart[0] += __mul24(ixv, ixv); apart[1] += __mul24(ixv, iyv); apart[2] += __mul24(iyv, iyv);
+                if (k & 1) {
+                    IxP[k >> 1] = __builtin_amdgcn_perm((uint32_t)ixv, IxP[k >> 1], 0x05040100u);   // (even pixel | odd pixel << 16)
+                    IyP[k >> 1] = __builtin_amdgcn_perm((uint32_t)iyv, IyP[k >> 1], 0x05040100u);
+                    apart[0] = dot2_acc(IxP[k >> 1], IxP[k >> 1], apart[0]);
+                    apart[1] = dot2_acc(IxP[k >> 1], IyP[k >> 1], apart[1]);
+                    apart[2] = dot2_acc(IyP[k >> 1], IyP[k >> 1], apart[2]);
+                } else { IxP[k >> 1] = (uint32_t)ixv; IyP[k >> 1] = (uint32_t)iyv; }
                 pc = pn; xc = xn; yc = yn;
             }
         }
@@ -454,11 +471,13 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 const uint32_t W0 = pack_weights(iw00, iw10), W1 = pack_weights(iw01, iw11);
                 uint32_t pc = PACKED_COLUMN(ja, jb, 0);
 #pragma unroll
-                for (int k = 0; k < PP; k++) {
-                    const uint32_t pn = PACKED_COLUMN(ja, jb, k + 1);
-                    const int diff = dot2_acc(pn, W1, dot2_acc(pc, W0, Iv[k])) >> 9;
-                    bpart[0] += __mul24(diff, Ix[k]); bpart[1] += __mul24(diff, Iy[k]);
-                    pc = pn;
+                for (int k = 0; k < PP; k += 2) {   // |diff| <= 8160: two of them per register, one dot product per sum and pixel pair
+                    const uint32_t p1 = PACKED_COLUMN(ja, jb, k + 1), p2 = PACKED_COLUMN(ja, jb, k + 2);
+                    const int diff0 = dot2_acc(p1, W1, dot2_acc(pc, W0, Iv[k])) >> 9;
+                    const int diff1 = dot2_acc(p2, W1, dot2_acc(p1, W0, Iv[k + 1])) >> 9;
+                    const uint32_t dp = __builtin_amdgcn_perm((uint32_t)diff1, (uint32_t)diff0, 0x05040100u);
+                    bpart[0] = dot2_acc(dp, IxP[k >> 1], bpart[0]); bpart[1] = dot2_acc(dp, IyP[k >> 1], bpart[1]);
+                    pc = p2;
                 }
             }
             LSTAMP(10);
@@ -686,6 +705,7 @@ __global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ s
     __shared__ float sC[36 * 36 * 3];
     __shared__ float sE[34 * 34];
     __shared__ unsigned smax[4];
+    BACKEND_PRIO();   // a short pass between two LK launches of its sequence: ahead of the bulk LK waves it shares SIMDs with
     const int cell = blockIdx.z;
     const int cx0 = cells[CELL_STRIDE * cell], cy0 = cells[CELL_STRIDE * cell + 1], cw = cells[CELL_STRIDE * cell + 2], ch = cells[CELL_STRIDE * cell + 3];
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
@@ -783,6 +803,7 @@ __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cell
                                                     int unlimited, int* __restrict__ out_xy, int* __restrict__ out_count, int* __restrict__ flags) {
     __shared__ unsigned long long lkey[GP_REG];
     __shared__ unsigned long long wbest[2][4];
+    BACKEND_PRIO();
     const int cell = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cw = cells[CELL_STRIDE * cell + 2];
     float* cv = cand_val + (size_t)cell * CELL_PIX;

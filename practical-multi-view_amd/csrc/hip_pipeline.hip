@@ -306,10 +306,14 @@ int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* param
     pmv::BatchEngine* eng = nullptr;
     int rc = pmv::batch_engine_get(ctx, B, &eng);
     if (rc != PMV_OK) return rc;
-    for (int b = 0; b < B; b++)
-        if (params[b].build_pyramids) { rc = pmv_frames_build(ctx, first_slot[b], params[b].n_frames); if (rc != PMV_OK) return rc; }
     rc = pmv_sync(ctx);
     if (rc != PMV_OK) return rc;
+    {   // the pyramids are built in the background, round by round, while the sequences already track
+        std::vector<int> nf((size_t)B), bd((size_t)B);
+        for (int b = 0; b < B; b++) { nf[(size_t)b] = params[b].n_frames; bd[(size_t)b] = params[b].build_pyramids; }
+        rc = pmv::engine_build_begin(eng, B, first_slot, nf.data(), bd.data());
+        if (rc != PMV_OK) return rc;
+    }
     std::vector<int> codes(B, PMV_OK);
     std::vector<std::string> msgs(B);
     std::vector<std::thread> th;
@@ -346,6 +350,8 @@ int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* param
             }
         });
     for (auto& t : th) t.join();
+    rc = pmv::engine_build_end(eng);
+    if (rc != PMV_OK) { pmv::set_err(ctx, "pmv_pipeline_run_batch: the background pyramid build failed"); for (int k = 0; k < B; k++) { delete out[k]; out[k] = nullptr; } return rc; }
     for (int b = 0; b < B; b++)
         if (codes[b] != PMV_OK) {
             pmv::set_err(ctx, "pmv_pipeline_run_batch: sequence %d: %s", b, msgs[b].c_str());

@@ -16,7 +16,7 @@ namespace pmv {
 
 struct Ingest {
     static constexpr int CHUNK = 16;   // frames per chunk: 7.5 MB at 1241x376 — large enough for DMA efficiency, small enough to start early
-    static constexpr int NBUF = 4;     // pinned ring depth
+    static constexpr int NBUF = 4;     // pinned ring depth (NBUF * CHUNK == pmv_ctx::TIGHT_FRAMES: the device landing area is the same ring)
     hipStream_t stream = nullptr;
     uint8_t* h_ring = nullptr;         // NBUF * CHUNK * frame bytes, pinned (kept across runs)
     size_t ring_frame_bytes = 0;
@@ -60,12 +60,12 @@ static void ingest_thread(pmv_ctx* ctx) {
             memcpy(stage, hsrc, (size_t)nb * fb);
             hsrc = stage;
         }
-        for (int i = 0; i < nb; i++) {
-            e = hipMemcpyAsync(ctx->d_slots + (size_t)(g->first_slot + f0 + i) * L.slot_bytes + L.gray_off, hsrc + (size_t)i * fb, fb, hipMemcpyHostToDevice, g->stream);
-            if (e != hipSuccess) { ingest_fail(g, PMV_ERR_HIP, "hipMemcpyAsync", e); return; }
-        }
+        // one contiguous copy per chunk into the landing area (a ring of NBUF chunk-sized regions, reused in stream order), level 0 from there
+        uint8_t* land = ctx->d_tight + (size_t)buf * Ingest::CHUNK * fb;
+        e = hipMemcpyAsync(land, hsrc, (size_t)nb * fb, hipMemcpyHostToDevice, g->stream);
+        if (e != hipSuccess) { ingest_fail(g, PMV_ERR_HIP, "hipMemcpyAsync", e); return; }
         if ((e = hipEventRecord(g->buf_free[buf], g->stream)) != hipSuccess) { ingest_fail(g, PMV_ERR_HIP, "hipEventRecord", e); return; }
-        if (build_levels_on(ctx, g->stream, g->first_slot + f0, nb, L) != PMV_OK) { ingest_fail(g, PMV_ERR_HIP, "pyramid launch", hipGetLastError()); return; }
+        if (build_levels_on(ctx, g->stream, g->first_slot + f0, nb, L, land) != PMV_OK) { ingest_fail(g, PMV_ERR_HIP, "pyramid launch", hipGetLastError()); return; }
         if ((e = hipEventRecord(g->ready[c], g->stream)) != hipSuccess) { ingest_fail(g, PMV_ERR_HIP, "hipEventRecord", e); return; }
         {
             std::lock_guard<std::mutex> lk(g->mu);

@@ -31,6 +31,10 @@ struct pmv_ctx {
     pmv::PyrLayout cap;                       // geometry of the largest frame; cap.slot_bytes = slot pitch
     std::vector<pmv::PyrLayout> slot_layout;  // per slot: n_levels 0 = empty, <0 = staged only, >0 = pyramid built
     uint8_t* d_slots = nullptr;
+    // landing area of host frames on their way into the slots: TIGHT_FRAMES tight gray frames (H2D copies are contiguous; k_pad_level0 takes
+    // level 0 from here). A 2-D copy straight into the padded level is a DMA per image row: 128 x 1101 frames did not finish in 200 s.
+    static constexpr int TIGHT_FRAMES = 64;
+    uint8_t* d_tight = nullptr;
     // LK
     float *d_prev_xy = nullptr, *d_out_xy = nullptr, *d_err = nullptr;
     uint8_t* d_status = nullptr;
@@ -71,8 +75,10 @@ PyrLayout make_layout(int w, int h);
 int backend_create(pmv_ctx* c);     // allocates PnP/BA workspaces
 void backend_destroy(pmv_ctx* c);
 // pyramid levels of `n` consecutive slots with identical geometry L, on `stream` (pmv_frames_build and the ingest thread)
-int build_levels_on(pmv_ctx* ctx, hipStream_t stream, int first_slot, int n, const PyrLayout& L);
+int build_levels_on(pmv_ctx* ctx, hipStream_t stream, int first_slot, int n, const PyrLayout& L, const uint8_t* tight = nullptr);
 PyrLayout layout_for(pmv_ctx* ctx, int w, int h);
+// pmv_frames_build on a given stream (no host synchronisation)
+int pmv_frames_build_on(pmv_ctx* ctx, hipStream_t stream, int first_slot, int n);
 // streamed ingest: make the front-end stream wait until `slot` has been copied and its pyramid built (no-op without a stream)
 int ingest_require(pmv_ctx* ctx, int slot);
 void ingest_destroy(pmv_ctx* ctx);

@@ -17,7 +17,7 @@ struct PyrLayout {
     int n_levels;                 // levels actually built = maxLevel + 1
     int w[MAX_LEVELS], h[MAX_LEVELS], stride[MAX_LEVELS];
     uint32_t off[MAX_LEVELS];     // byte offset of the padded level buffer inside the slot
-    uint32_t gray_off;            // byte offset of the staged tight gray frame (w0*h0 bytes)
+    uint32_t gray_off;            // byte offset of pixel (0,0) of level 0: a frame is staged straight into the interior of its padded level 0 (row pitch stride[0])
     uint32_t slot_bytes;
 };
 
@@ -105,7 +105,7 @@ struct LKParams {
 struct LKSeq { unsigned long long prev_off, next_off; };   // byte offsets of a sequence's prev / next frame slot (k_lk_batch)
 hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_seqs, const int2* d_blocks, int n_blocks, const PyrLayout& L,
                            const float* d_prev_xy, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err);
-hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n);
+hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n, const uint8_t* tight = nullptr /* tight gray frames to take level 0 from; null: in place */);
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int level_dst, int first_slot, int n);
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
                      const float* d_prev_xy, const int* d_order, int n_blocks, int n, const LKParams& P, float* d_out_xy,
@@ -114,6 +114,12 @@ hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* nex
 // Detector cells on the device: CELL_STRIDE ints per cell = (x0, y0, w, h, frame slot index, 0, 0, 0) — the slot index lets one
 // launch serve cells of different frames (several sequences in one batch); `slots` is the base of the frame-slot array.
 constexpr int CELL_STRIDE = 8;
+// The back-end chains (PnP hypotheses + refit, the ~23 launches of an LM solve, two-view DLT) and the detector's selection pass are short,
+// serially dependent launches whose waves share SIMDs with thousands of LK waves that keep the vector ALU issuing: in the mix every k_bamB_*
+// kernel ran 3-4x longer than alone (kernel trace of a B = 128 run: campoint 64 vs 18 us, backsub 69 vs 15 us, no dispatch gap between them).
+// s_setprio raises the issue priority of the wave that executes it, so the few waves of a chain get the instruction slots they ask for and the
+// LK waves fill the rest.
+#define BACKEND_PRIO() __builtin_amdgcn_s_setprio(3)
 // GFTT: eig maps (n_cells * 255*255 floats), cell max (n_cells uint32 ordered keys), outputs
 hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                        int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,

@@ -21,15 +21,16 @@ for b in range(Bmax):
 ref = None
 THREADED = int(os.environ.get("THREADED", "1"))
 DEVFP = int(os.environ.get("DEVFP", "0"))
+BA_IT = int(os.environ.get("BA_ITERS", "5"))   # diagnostic: how sensitive is the throughput to the length of the BA launch chain
 print("wait mode", os.environ.get("PMV_BATCH_WAIT", "flag"), "threaded", THREADED, flush=True)
 for B in Bs:
     seqs = [(b * n, n, gt) for b in range(B)]
-    r = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED, device_fivepoint=DEVFP)   # warm-up
+    r = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED, device_fivepoint=DEVFP, ba_iterations=BA_IT)   # warm-up
     ctx.sync()
     s0 = ctx.batch_stats()
     t0 = time.perf_counter()
     c0 = time.process_time()
-    r2 = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED, device_fivepoint=DEVFP)
+    r2 = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED, device_fivepoint=DEVFP, ba_iterations=BA_IT)
     ctx.sync()
     dt = time.perf_counter() - t0
     cpu = time.process_time() - c0
