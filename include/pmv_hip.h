@@ -59,8 +59,9 @@ int pmv_sync(pmv_ctx* ctx);               /* waits for both streams */
  * with winSize 32, maxLevel 4). */
 int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, int stride);
 /* Batch form: n frames, tightly packed (n*w*h bytes), into slots first_slot..first_slot+n-1. The gray data
- * is staged to HBM first (pmv_frames_stage), the pyramids are built by pmv_frames_build so that a benchmark can
- * time the build with inputs already resident in HBM. */
+ * is staged to HBM first (pmv_frames_stage: level 0 of each slot; a slot keeps no second copy of the frame), the pyramids are
+ * built by pmv_frames_build (level 0's REFLECT_101 frame in place + the levels above) so that a benchmark can time the build with
+ * inputs already resident in HBM. */
 int pmv_frames_stage(pmv_ctx* ctx, int first_slot, int n, const uint8_t* gray, int w, int h);
 int pmv_frames_build(pmv_ctx* ctx, int first_slot, int n);
 /* Streamed ingest (Frame::Frame / Frame::init + the front-end's per-frame load, Frame.cpp:31-42, OdometryPipeline.cpp:212-220):

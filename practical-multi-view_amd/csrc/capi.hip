@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 using namespace pmv;
 
@@ -360,6 +361,8 @@ int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int m
     pack_cells(ctx->h_cells, cells, n_cells, slot);
     CKC(hipMemcpyAsync(ctx->d_cells, ctx->h_cells, (size_t)n_cells * CELL_STRIDE * 4, hipMemcpyHostToDevice, ctx->s_front));
     CKC(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->s_front));   // overflow bits are per call: one overflow must not poison later calls
+    static const bool gftt_dbg = getenv("PMV_GFTT_DBG") != nullptr;
+    if (gftt_dbg) { const int on = 0x40000000; CKC(hipMemcpyAsync(ctx->d_flags, &on, 4, hipMemcpyHostToDevice, ctx->s_front)); }
     CKC(launch_gftt(ctx->s_front, ctx->d_slots, L, ctx->d_cells, n_cells, max_per_cell, quality,
                     min_dist, unlimited, (float*)ctx->d_eig, (unsigned*)ctx->d_cellmax, ctx->d_det_xy, ctx->d_det_count, ctx->d_flags, ctx->d_spill));
     const size_t nxy = (size_t)n_cells * max_per_cell * 8;
@@ -367,6 +370,12 @@ int pmv_detect_gftt(pmv_ctx* ctx, int slot, const int* cells, int n_cells, int m
     CKC(hipMemcpyAsync(ctx->h_det_count, ctx->d_det_count, (size_t)n_cells * 4, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipMemcpyAsync(ctx->h_det_count + MAX_CELLS, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->s_front));
     CKC(hipStreamSynchronize(ctx->s_front));
+    if (gftt_dbg) {
+        int f[4];
+        CKC(hipMemcpy(f, ctx->d_flags, 16, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[gftt-dbg] cell 0: %d raw records, %d above the threshold; cycles: compaction %d, key set-up %d, rounds %d\n", f[0] & 0xffff, (f[0] >> 16) & 0x3fff, f[1], f[2], f[3]);
+        ctx->h_det_count[MAX_CELLS] &= ~0x40000000;
+    }
     REQ((ctx->h_det_count[MAX_CELLS] & 4) == 0, PMV_ERR_OVERFLOW, "pmv_detect_gftt: more than %d corners in a cell with max_per_cell <= 0 (no limit)", MAX_PER_CELL);
     memcpy(out_xy, ctx->h_det_xy, nxy);
     memcpy(out_count, ctx->h_det_count, (size_t)n_cells * 4);

@@ -708,7 +708,10 @@ __global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ s
     BACKEND_PRIO();   // a short pass between two LK launches of its sequence: ahead of the bulk LK waves it shares SIMDs with
     const int cell = blockIdx.z;
     const int cx0 = cells[CELL_STRIDE * cell], cy0 = cells[CELL_STRIDE * cell + 1], cw = cells[CELL_STRIDE * cell + 2], ch = cells[CELL_STRIDE * cell + 3];
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+    // Consecutive workgroup ids go round the 8 XCDs, each with its own L2: blockIdx.x (8 values = the XCD) is the tile ROW, so the eight
+    // tiles that share the 128-byte lines of a 32-row band of the image run on ONE XCD and the band is fetched from HBM once (with
+    // blockIdx.x as the tile column every line was fetched by four XCDs: 2.75 MB of HBM reads per 0.47 MB frame by the PMC counters)
+    const int tx0 = blockIdx.y * 32, ty0 = blockIdx.x * 32;
     if (tx0 >= cw || ty0 >= ch) return;
     const uint8_t* img = level_origin(slots + (size_t)cells[CELL_STRIDE * cell + 4] * L.slot_bytes, L, 0);
     const int st = L.stride[0];
@@ -797,13 +800,17 @@ __global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ s
 // one is closer than minDistance") runs as: repeat {arg-max over the live records; accept; kill every record closer than minDistance} -
 // identical result, max_corners rounds of register work with one 4-wavefront exchange each, no sort. A cell with more than GP_REG records
 // above the threshold (a periodic texture can make every pixel a local maximum) takes the same rounds over its list in HBM.
-constexpr int GP_T = 256, GP_SLOTS = 16, GP_REG = GP_T * GP_SLOTS;
+constexpr int GP_T = 256, GP_SLOTS = 16, GP_REG = GP_T * GP_SLOTS, GP_MAXOUT = 4096;   // GP_MAXOUT = MAX_PER_CELL of pmv_ctx.h
 __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cells, float* __restrict__ cand_val, unsigned* __restrict__ cand_idx,
                                                     const unsigned* __restrict__ cellinfo, int max_corners, double quality, double min_dist,
                                                     int unlimited, int* __restrict__ out_xy, int* __restrict__ out_count, int* __restrict__ flags) {
     __shared__ unsigned long long lkey[GP_REG];
-    __shared__ unsigned long long wbest[2][4];
+    __shared__ __attribute__((aligned(16))) unsigned long long wbest[2][4];
+    // accepted corners, (y << 16) | x, written to HBM once at the end: a global store per round sits in front of the next round's barrier
+    // (__syncthreads waits for the wavefront's outstanding stores: 1-2 us each - 80 of the 93 us this kernel took with the store inside the loop)
+    __shared__ unsigned s_acc[GP_MAXOUT];
     BACKEND_PRIO();
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter();
     const int cell = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cw = cells[CELL_STRIDE * cell + 2];
     float* cv = cand_val + (size_t)cell * CELL_PIX;
@@ -814,82 +821,121 @@ __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cell
     // compaction of the records above the threshold: key = (value bits, pixel index), 0 = dead. The first GP_REG go to LDS, the rest
     // stay in the HBM list, compacted in place (a record only moves to a lower position, behind every record already read)
     int n = 0;
-    for (int base = 0; base < nraw; base += GP_T) {
-        const int i = base + tid;
-        float v = 0.f; unsigned px = 0;
-        if (i < nraw) { v = cv[i]; px = ci[i]; }
-        const bool keep = i < nraw && v > thr;
+    constexpr int CPT = 4;   // records per thread and chunk: a quarter of the barriers
+    for (int base = 0; base < nraw; base += GP_T * CPT) {
+        float v[CPT]; unsigned px[CPT]; bool keep[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; q++) {
+            const int i = base + q * GP_T + tid;
+            v[q] = 0.f; px[q] = 0;
+            if (i < nraw) { v[q] = cv[i]; px[q] = ci[i]; }
+            keep[q] = i < nraw && v[q] > thr;
+        }
         __syncthreads();   // (all reads of this chunk before any in-place write into it)
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) wbest[0][wave] = (unsigned long long)__popcll(bal);
+        // place in the compacted list = records kept so far + those of the wavefronts before + those of this wavefront's earlier turns + rank
+        // in the ballot (any order will do, the selection is order-free; every target position lies inside the part already read)
+        int wave_tot = 0;
+#pragma unroll
+        for (int q = 0; q < CPT; q++) wave_tot += __popcll(__ballot(keep[q]));
+        if (lane == 0) wbest[0][wave] = (unsigned long long)wave_tot;
         __syncthreads();
         int off = n;
         for (int w2 = 0; w2 < wave; w2++) off += (int)wbest[0][w2];
         const int tot = (int)(wbest[0][0] + wbest[0][1] + wbest[0][2] + wbest[0][3]);
-        if (keep) {
-            const int slot = off + __popcll(bal & ((1ull << lane) - 1ull));
-            if (slot < GP_REG) lkey[slot] = ((unsigned long long)__float_as_uint(v) << 32) | px;
-            else { cv[slot] = v; ci[slot] = px; }
+        int run = 0;
+#pragma unroll
+        for (int q = 0; q < CPT; q++) {
+            const unsigned long long bal = __ballot(keep[q]);
+            if (keep[q]) {
+                const int slot = off + run + __popcll(bal & ((1ull << lane) - 1ull));
+                if (slot < GP_REG) lkey[slot] = ((unsigned long long)__float_as_uint(v[q]) << 32) | px[q];
+                else { cv[slot] = v[q]; ci[slot] = px[q]; }
+            }
+            run += __popcll(bal);
         }
         n += tot;
     }
     __syncthreads();
+    const unsigned long long dbg_t1 = __builtin_readcyclecounter();
     const bool use_dist = min_dist >= 1.0;
     const double md2 = min_dist * min_dist;
     // dx*dx + dy*dy is an integer: (double)d2 < md2  <=>  d2 < ceil(md2)
     const int md2i = (int)(md2 < 2.0e9 ? ceil(md2) : 2.0e9);
     const int n_reg = n < GP_REG ? n : GP_REG;
-    unsigned long long key[GP_SLOTS];
-    int kxy[GP_SLOTS];   // (y << 16) | x of the slot's pixel: the divisions by the cell width happen once, not in every round
+    // A record in registers = (value bits, (y << 16) | x): the pair orders like (value, pixel index = y * cw + x), the coordinates need no
+    // division by the cell width in the rounds, and every comparison is a full-rate 32-bit one (v_cmp / v_cndmask on 64-bit keys are not)
+    unsigned kv[GP_SLOTS], kp[GP_SLOTS];   // kv == 0: dead / empty (live values are > 0)
 #pragma unroll
     for (int s2 = 0; s2 < GP_SLOTS; s2++) {
         const int i = s2 * GP_T + tid;
-        key[s2] = i < n_reg ? lkey[i] : 0ull;
-        const int px = (int)(key[s2] & 0x7fffffffu);
+        const unsigned long long k = i < n_reg ? lkey[i] : 0ull;
+        kv[s2] = (unsigned)(k >> 32);
+        const int px = (int)(k & 0x7fffffffu);
         const int y = px / cw;
-        kxy[s2] = (y << 16) | (px - y * cw);
+        kp[s2] = ((unsigned)y << 16) | (unsigned)(px - y * cw);
     }
+    unsigned* wv = (unsigned*)&wbest[0][0];   // [2][4] values, then [2][4] positions
+    unsigned* wp = wv + 8;
     int naccepted = 0;
+    const unsigned long long dbg_t2 = __builtin_readcyclecounter();
+    const int nslots = (n_reg + GP_T - 1) / GP_T;   // slots in use (uniform): a typical cell keeps ~750 records = 3 of the 16
+    unsigned bv = 0, bp = 0;                        // this lane's best live record; recomputed only after one of its records died
+#pragma unroll
+    for (int s2 = 0; s2 < GP_SLOTS; s2++) { const bool g = kv[s2] > bv || (kv[s2] == bv && kp[s2] > bp); bv = g ? kv[s2] : bv; bp = g ? kp[s2] : bp; }
     for (int it = 0; it < max_corners; it++) {
-        unsigned long long best = 0;
-#pragma unroll
-        for (int s2 = 0; s2 < GP_SLOTS; s2++) best = key[s2] > best ? key[s2] : best;
-        for (int i = GP_REG + tid; i < n; i += GP_T) {   // (only for cells beyond the register capacity)
+        unsigned tv = bv, tp = bp;
+        for (int i = GP_REG + tid; i < n; i += GP_T) {   // (only for cells beyond the register capacity: records in HBM, bit 31 of the index = dead)
             const unsigned px = ci[i];
-            if (!(px >> 31)) { const unsigned long long k = ((unsigned long long)__float_as_uint(cv[i]) << 32) | px; best = k > best ? k : best; }
+            if (px >> 31) continue;
+            const unsigned v = __float_as_uint(cv[i]);
+            const int y = (int)px / cw;
+            const unsigned pp = ((unsigned)y << 16) | (unsigned)((int)px - y * cw);
+            const bool g = v > tv || (v == tv && pp > tp);
+            tv = g ? v : tv; tp = g ? pp : tp;
         }
-        best = wave_max_u64(best);
-        if (lane == 0) wbest[it & 1][wave] = best;
+        // arg-max over the workgroup: first the value, then the position among the lanes that hold that value
+        const unsigned mv = wave_max_u32(tv);
+        const unsigned mp = wave_max_u32(tv == mv ? tp : 0u);
+        if (lane == 0) { wv[(it & 1) * 4 + wave] = mv; wp[(it & 1) * 4 + wave] = mp; }
         __syncthreads();   // (one barrier per round: the exchange buffer alternates)
-        unsigned long long b = wbest[it & 1][0];
-#pragma unroll
-        for (int i = 1; i < 4; i++) b = wbest[it & 1][i] > b ? wbest[it & 1][i] : b;
-        if (b == 0) break;
-        const int bidx = (int)(b & 0x7fffffffu);
-        const int by = bidx / cw, bx = bidx - by * cw;
-        if (tid == 0) {
-            out_xy[((size_t)cell * max_corners + naccepted) * 2] = bx;
-            out_xy[((size_t)cell * max_corners + naccepted) * 2 + 1] = by;
-        }
+        const uint4 v4 = *(const uint4*)&wv[(it & 1) * 4], p4 = *(const uint4*)&wp[(it & 1) * 4];
+        const unsigned V = max(max(v4.x, v4.y), max(v4.z, v4.w));
+        if (V == 0) break;
+        const unsigned P = max(max(v4.x == V ? p4.x : 0u, v4.y == V ? p4.y : 0u), max(v4.z == V ? p4.z : 0u, v4.w == V ? p4.w : 0u));
+        const int bx = (int)(P & 0xffffu), by = (int)(P >> 16);
+        if (tid == 0) s_acc[naccepted] = P;
         naccepted++;
+        bool died = false;
 #pragma unroll
         for (int s2 = 0; s2 < GP_SLOTS; s2++) {
+            if (s2 >= nslots) break;   // uniform
             bool kill;
             if (use_dist) {
-                const int dx = (kxy[s2] & 0xffff) - bx, dy = (kxy[s2] >> 16) - by;
+                const int dx = (int)(kp[s2] & 0xffffu) - bx, dy = (int)(kp[s2] >> 16) - by;
                 kill = dx * dx + dy * dy < md2i;
-            } else kill = (int)(key[s2] & 0x7fffffffu) == bidx;
-            if (kill) key[s2] = 0;
+            } else kill = kp[s2] == P;
+            kill = kill && kv[s2] != 0;
+            if (kill) kv[s2] = 0;
+            died = died || kill;
+        }
+        if (died) {
+            bv = 0; bp = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < GP_SLOTS; s2++) {
+                if (s2 >= nslots) break;
+                const bool g = kv[s2] > bv || (kv[s2] == bv && kp[s2] > bp);
+                bv = g ? kv[s2] : bv; bp = g ? kp[s2] : bp;
+            }
         }
         for (int i = GP_REG + tid; i < n; i += GP_T) {
             const unsigned u = ci[i];
             if (u >> 31) continue;
             bool kill;
+            const int y = (int)u / cw, x = (int)u - y * cw;
             if (use_dist) {
-                const int y = (int)u / cw, x = (int)u - y * cw;
                 const int dx = x - bx, dy = y - by;
-                kill = (double)(dx * dx + dy * dy) < md2;
-            } else kill = (int)u == bidx;
+                kill = dx * dx + dy * dy < md2i;
+            } else kill = x == bx && y == by;
             if (kill) ci[i] = u | 0x80000000u;
         }
     }
@@ -898,9 +944,19 @@ __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cell
     if (unlimited && naccepted == max_corners) {
         int live = 0;
 #pragma unroll
-        for (int s2 = 0; s2 < GP_SLOTS; s2++) live |= key[s2] != 0;
+        for (int s2 = 0; s2 < GP_SLOTS; s2++) live |= kv[s2] != 0;
         for (int i = GP_REG + tid; i < n; i += GP_T) live |= !(ci[i] >> 31);
         if (live) atomicOr(flags, 4);
+    }
+    if (cell == 0 && tid == 0 && (flags[0] & 0x40000000)) {   // diagnostic (PMV_GFTT_DBG=1): cycles of compaction / key set-up / rounds, record counts
+        const unsigned long long dbg_t3 = __builtin_readcyclecounter();
+        flags[1] = (int)(dbg_t1 - dbg_t0); flags[2] = (int)(dbg_t2 - dbg_t1); flags[3] = (int)(dbg_t3 - dbg_t2);
+        flags[0] = 0x40000000 | (nraw & 0xffff) | ((n & 0x3fff) << 16);
+    }
+    __syncthreads();
+    for (int i = tid; i < naccepted; i += GP_T) {
+        const unsigned a = s_acc[i];   // (y << 16) | x
+        *(int2*)&out_xy[((size_t)cell * max_corners + i) * 2] = make_int2((int)(a & 0xffffu), (int)(a >> 16));
     }
     if (tid == 0) out_count[cell] = naccepted;
 }
@@ -908,7 +964,7 @@ __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cell
 hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, const int* d_cells, int n_cells,
                        int max_per_cell, double quality, double min_dist, int unlimited, float* d_eig, unsigned* d_cellmax,
                        int* d_out_xy, int* d_out_count, int* d_flags, unsigned* d_spill) {
-    if (!slots || !d_cells || !d_eig || !d_cellmax || !d_out_xy || !d_out_count || !d_flags || !d_spill || n_cells < 1 || max_per_cell < 1) return hipErrorInvalidValue;
+    if (!slots || !d_cells || !d_eig || !d_cellmax || !d_out_xy || !d_out_count || !d_flags || !d_spill || n_cells < 1 || max_per_cell < 1 || max_per_cell > GP_MAXOUT) return hipErrorInvalidValue;
     // d_eig / d_spill: the cells' candidate records (value / pixel index, CELL_PIX each); d_cellmax: (maximum key, record count) per cell
     hipError_t e = hipMemsetAsync(d_cellmax, 0, 2 * sizeof(unsigned) * n_cells, s);
     if (e != hipSuccess) return e;

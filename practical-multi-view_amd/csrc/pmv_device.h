@@ -83,13 +83,41 @@ __device__ inline double wave_sum_f64(double v) {
     v += dpp_f64(v, 3);   // row_mirror
     return (readlane_f64_c(v, 0) + readlane_f64_c(v, 16)) + (readlane_f64_c(v, 32) + readlane_f64_c(v, 48));
 }
-__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long t = __shfl_xor(v, o, 64);
-        v = t > v ? t : v;
+// Wavefront all-reduce maximum of 64-bit keys on the same DPP row operations (the __shfl_xor form was six dependent pairs of ds_bpermute,
+// ~1.5 k clk per call: most of a selection round of k_gftt_pick). Every lane receives the maximum.
+__device__ inline unsigned long long dpp_u64(unsigned long long v, const int ctrl_sel) {
+    int lo = (int)(unsigned)(v & 0xffffffffull), hi = (int)(unsigned)(v >> 32);
+    switch (ctrl_sel) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, false); break;
     }
-    return v;
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+// the same for 32-bit keys: one DPP move + v_max_u32 per step
+__device__ inline unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ inline unsigned long long readlane_u64(unsigned long long v, int l) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), l);
+}
+__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+    unsigned long long t;
+    t = dpp_u64(v, 0); v = t > v ? t : v;   // quad_perm [1,0,3,2]
+    t = dpp_u64(v, 1); v = t > v ? t : v;   // quad_perm [2,3,0,1]
+    t = dpp_u64(v, 2); v = t > v ? t : v;   // row_half_mirror
+    t = dpp_u64(v, 3); v = t > v ? t : v;   // row_mirror: every lane holds its 16-lane row's maximum
+    const unsigned long long a = readlane_u64(v, 0), b = readlane_u64(v, 16), c = readlane_u64(v, 32), d = readlane_u64(v, 48);
+    const unsigned long long ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
 // ---- launch entry points (frontend.hip) -------------------------------------------------------------------
