@@ -236,7 +236,7 @@ def main():
         if multi:
             out = []
             for i in range(0, len(seq_slots), WAVE):
-                out += ctx.pipeline_run_batch(seq_slots[i: i + WAVE], w, h, K, threaded=0, **batch_kw)
+                out += ctx.pipeline_run_batch(seq_slots[i: i + WAVE], w, h, K, threaded=0 if args.sequential else 1, **batch_kw)
             return out
         frames, gt = data[0]
         return [ctx.pipeline_run(frames.shape[0], w, h, K, gt, build_pyramids=1, host_frames=frames if host else None, **run_kw)]

@@ -58,6 +58,9 @@ int pmv_sync(pmv_ctx* ctx);               /* waits for both streams */
 /* Copy one 8-bit gray frame (host) into `slot` and build its LK pyramid (levels as cv::buildOpticalFlowPyramid
  * with winSize 32, maxLevel 4). */
 int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, int stride);
+/* The same from a colour image as Frame::Frame(file) reads it (Frame.cpp:33: imread(IMREAD_COLOR) = 8-bit BGR, `stride` bytes per row):
+ * cv::cvtColor(BGR2GRAY) (Frame.cpp:40-41) runs on the device, then the pyramid as above. Identity for B = G = R (KITTI's gray PNGs). */
+int pmv_frame_upload_bgr(pmv_ctx* ctx, int slot, const uint8_t* bgr, int w, int h, int stride);
 /* Batch form: n frames, tightly packed (n*w*h bytes), into slots first_slot..first_slot+n-1. The gray data
  * is staged to HBM first (pmv_frames_stage: level 0 of each slot; a slot keeps no second copy of the frame), the pyramids are
  * built by pmv_frames_build (level 0's REFLECT_101 frame in place + the levels above) so that a benchmark can time the build with

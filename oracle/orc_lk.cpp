@@ -238,6 +238,15 @@ void lk_track(const Image8& prev, const Image8& next, const float* prev_xy, int 
 extern "C" {
 
 // out must hold ((w+1)/2)*((h+1)/2) bytes
+// cv::cvtColor(BGR2GRAY) on 8-bit pixels (Frame::init, Frame.cpp:40-41) [mem: OpenCV 3.4 color.cpp, RGB2Gray<uchar>: 14-bit fixed point,
+// B2Y = 1868, G2Y = 9617, R2Y = 4899, CV_DESCALE(.., 14)]. Parity unpinned like the other OpenCV rows; identity for B = G = R.
+void orc_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* out) {
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* p = bgr + (size_t)y * stride + 3 * x;
+            out[(size_t)y * w + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+        }
+}
 void orc_pyr_down(const uint8_t* src, int w, int h, uint8_t* out) {
     orc::Image8 s(w, h);
     memcpy(s.d.data(), src, (size_t)w * h);

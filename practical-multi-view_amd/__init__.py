@@ -34,7 +34,7 @@ class BaSummary(C.Structure):
 # every symbol include/pmv_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
-    "pmv_frame_upload", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_get_level_padded", "pmv_frame_num_levels",
+    "pmv_frame_upload", "pmv_frame_upload_bgr", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_get_level_padded", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_detect_fast", "pmv_knn_match", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
     "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates", "pmv_triangulate_candidates_ahead", "pmv_fivepoint_hypotheses",
     "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
@@ -231,6 +231,12 @@ class Context:
     def frame_upload(self, slot, gray):
         g = np.ascontiguousarray(gray, np.uint8)
         self._ck(self.lib.pmv_frame_upload(self.h, slot, _p(g, _u8p), g.shape[1], g.shape[0], g.shape[1]))
+
+    def frame_upload_bgr(self, slot, bgr):
+        """(h, w, 3) uint8 BGR image as cv::imread(IMREAD_COLOR) gives it: BGR2GRAY on the device, then the pyramid"""
+        b = np.ascontiguousarray(bgr, np.uint8)
+        assert b.ndim == 3 and b.shape[2] == 3
+        self._ck(self.lib.pmv_frame_upload_bgr(self.h, slot, _p(b, _u8p), b.shape[1], b.shape[0], 3 * b.shape[1]))
 
     def frames_stage(self, first_slot, frames):
         f = np.ascontiguousarray(frames, np.uint8)

@@ -242,6 +242,26 @@ int pmv_frame_upload(pmv_ctx* ctx, int slot, const uint8_t* gray, int w, int h, 
     return PMV_OK;
 }
 
+// Frame::Frame(file) + Frame::init for a COLOUR image (Frame.cpp:33,40-41: imread(IMREAD_COLOR) gives BGR, cvtColor(BGR2GRAY) the u8 `bw`
+// everything else works on): the conversion runs on the device, in front of the landing area.
+int pmv_frame_upload_bgr(pmv_ctx* ctx, int slot, const uint8_t* bgr, int w, int h, int stride) {
+    REQ(ctx && bgr, PMV_ERR_INVALID, "pmv_frame_upload_bgr: null argument");
+    REQ(slot >= 0 && slot < ctx->n_slots, PMV_ERR_CAPACITY, "pmv_frame_upload_bgr: slot %d out of range", slot);
+    REQ(w >= 40 && h >= 40 && w <= ctx->max_w && h <= ctx->max_h && stride >= 3 * w, PMV_ERR_CAPACITY, "pmv_frame_upload_bgr: frame %dx%d outside capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+    tl_prof = &ctx->prof;
+    CKC(hipSetDevice(ctx->device));
+    PyrLayout L = layout_for(ctx, w, h);
+    // landing area: frame 0 receives the gray image, frames 1..3 hold the three bytes per pixel on their way in (TIGHT_FRAMES >= 4)
+    uint8_t* d_bgr = ctx->d_tight + (size_t)ctx->max_w * ctx->max_h;
+    CKC(hipMemcpy2DAsync(d_bgr, (size_t)3 * w, bgr, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, ctx->s_front));
+    CKC(launch_bgr2gray(ctx->s_front, d_bgr, w, h, 3 * w, ctx->d_tight));
+    int rc = build_levels_on(ctx, ctx->s_front, slot, 1, L, ctx->d_tight);
+    if (rc) return rc;
+    CKC(hipStreamSynchronize(ctx->s_front));
+    ctx->slot_layout[slot] = L;
+    return PMV_OK;
+}
+
 int pmv_frame_num_levels(pmv_ctx* ctx, int slot) {
     if (!ctx || slot < 0 || slot >= ctx->n_slots) return PMV_ERR_INVALID;
     const int n = ctx->slot_layout[slot].n_levels;

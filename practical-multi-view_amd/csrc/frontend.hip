@@ -188,6 +188,30 @@ __global__ __launch_bounds__(PYR_T) void k_pyrdown(uint8_t* slots, PyrLayout L, 
     }
 }
 
+// cv::cvtColor(BGR2GRAY) for 8-bit images (Frame::init, Frame.cpp:40-41): gray = (B * 1868 + G * 9617 + R * 4899 + 8192) >> 14, the 14-bit
+// fixed-point form of 0.114 B + 0.587 G + 0.299 R [mem: OpenCV 3.4 color.cpp]; identity for B = G = R (KITTI's gray PNGs, quirk Q2).
+// One thread per 4 output pixels: 12 source bytes as three dword loads when the row is 4-byte aligned, byte loads otherwise.
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ bgr, int w, int h, int stride, uint8_t* __restrict__ gray) {
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= w || y >= h) return;
+    const uint8_t* row = bgr + (size_t)y * stride + 3 * (size_t)x4;
+    uint8_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (x4 + k >= w) { out[k] = 0; continue; }
+        const int b = row[3 * k], g = row[3 * k + 1], r = row[3 * k + 2];
+        out[k] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+    }
+    uint8_t* dst = gray + (size_t)y * w + x4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (x4 + k < w) dst[k] = out[k];
+}
+hipError_t launch_bgr2gray(hipStream_t s, const uint8_t* d_bgr, int w, int h, int stride, uint8_t* d_gray) {
+    if (!d_bgr || !d_gray || w < 1 || h < 1 || stride < 3 * w) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bgr2gray, dim3((w + 1023) / 1024, h), dim3(256), 0, s, d_bgr, w, h, stride, d_gray);
+    return hipGetLastError();
+}
+
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n, const uint8_t* tight) {
     if (!slots || n < 1 || first_slot < 0 || L.n_levels < 1) return hipErrorInvalidValue;
     dim3 grid(1, (L.h[0] + 2 * PAD + PAD0_R - 1) / PAD0_R, n);

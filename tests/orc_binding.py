@@ -28,6 +28,13 @@ class Oracle:
         self.lib.orc_pyr_down(_p(img, _u8p), w, h, _p(out, _u8p))
         return out
 
+    def bgr2gray(self, bgr):
+        b = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = b.shape
+        out = np.zeros((h, w), np.uint8)
+        self.lib.orc_bgr2gray(_p(b, _u8p), w, h, 3 * w, _p(out, _u8p))
+        return out
+
     def scharr(self, img):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape

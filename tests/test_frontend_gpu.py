@@ -30,6 +30,25 @@ def test_pyramid_matches_oracle(pmv, orc, gpu_ctx_factory, cfg):
     assert min(ref.shape) <= 32 or nl == 4
 
 
+def test_colour_frame_upload_matches_oracle(pmv, orc, gpu_ctx_factory):
+    """Frame::Frame(file) / Frame::init (Frame.cpp:33,40-41): a BGR image through pmv_frame_upload_bgr gives the pyramid of the oracle's
+    BGR2GRAY image, at an odd width (unaligned rows, partial last thread) too; a gray image sent as BGR equals pmv_frame_upload."""
+    rng = np.random.default_rng(9)
+    for w, h in ((1241, 376), (333, 97)):
+        bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ctx = gpu_ctx_factory(w, h, n_slots=2, max_tracks=64)
+        ctx.frame_upload_bgr(0, bgr)
+        gray = orc.bgr2gray(bgr)
+        ctx.frame_upload(1, gray)
+        for l in range(ctx.num_levels(0) + 1):
+            assert np.array_equal(ctx.get_level(0, l, w, h), ctx.get_level(1, l, w, h)), (w, h, l)
+            assert np.array_equal(ctx.get_level_padded(0, l, w, h), ctx.get_level_padded(1, l, w, h))
+        assert np.array_equal(ctx.get_level(0, 0, w, h), gray)
+        g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        ctx.frame_upload_bgr(0, np.repeat(g[..., None], 3, axis=2))
+        assert np.array_equal(ctx.get_level(0, 0, w, h), g)
+
+
 @pytest.mark.parametrize("w,h", [(1241, 376), (1226, 370), (321, 163), (224, 131), (113, 97), (111, 80), (100, 66), (97, 67)])
 def test_pyramid_reflect101_frame(pmv, orc, gpu_ctx_factory, w, h):
     """every level carries a 64-pixel BORDER_REFLECT_101 frame (cv::buildOpticalFlowPyramid pads each level; LK reads it for windows

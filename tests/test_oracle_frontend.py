@@ -233,3 +233,16 @@ def test_shitomasi_signed_char_quirk_q1(orc):
     _, _, Rh = orc.shitomasi_cell(hi, (0, 0, 40, 40), 5, want_resp=True)
     assert np.nanmax(Rh) < np.nanmax(Rl)
     np.testing.assert_allclose(np.nanmax(Rh) / np.nanmax(Rl), (56.0 / 100.0) ** 2, rtol=1e-9)
+
+
+def test_bgr2gray_matches_numpy_and_is_identity_on_gray(orc):
+    """Frame::init's cvtColor(BGR2GRAY) (Frame.cpp:40-41): the oracle against a numpy twin of the 14-bit fixed-point formula; a gray
+    image stored as BGR (B = G = R: what imread(IMREAD_COLOR) makes of KITTI's PNGs) comes back unchanged (quirk Q2)."""
+    rng = np.random.default_rng(5)
+    bgr = rng.integers(0, 256, (57, 83, 3), dtype=np.uint8)
+    twin = ((bgr[..., 0].astype(np.int64) * 1868 + bgr[..., 1].astype(np.int64) * 9617 + bgr[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(orc.bgr2gray(bgr), twin)
+    g = rng.integers(0, 256, (40, 61), dtype=np.uint8)
+    assert np.array_equal(orc.bgr2gray(np.repeat(g[..., None], 3, axis=2)), g)
+    ramp = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(orc.bgr2gray(np.stack([ramp, ramp, ramp], -1)[None]), ramp[None])
