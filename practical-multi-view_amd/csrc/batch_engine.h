@@ -14,7 +14,10 @@ int engine_build_end(BatchEngine* E);
 void batch_engine_stats(BatchEngine* E, long long* counts10, double* times15);
 // same contracts as pmv_lk_track / pmv_detect_* / pmv_pnp_ransac / pmv_ba_solve / pmv_triangulate_candidates; `seq` selects the
 // sequence's back-end workspace set. Blocking; safe to call from many threads at once (one outstanding call per seq and stream role).
-int engine_lk(BatchEngine* E, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy, uint8_t* status, float* err);
+// predicted_iters (optional): how many LK iterations the caller expects each track to take (0..255) - the launch starts the expensive
+// tracks first; iters_out (optional): what each track took. Neither changes a result.
+int engine_lk(BatchEngine* E, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy, uint8_t* status, float* err,
+              const uint8_t* predicted_iters = nullptr, uint8_t* iters_out = nullptr);
 int engine_detect(BatchEngine* E, int kind /* 1 GFTT, 2 ShiTomasi */, int slot, const int* cells, int n_cells, int max_per_cell, double quality,
                   double min_dist, int* out_xy, double* out_score, int* out_count);
 int engine_pnp(BatchEngine* E, int seq, const float* obj_xyz, const float* img_xy, int m, const double* K, double* rvec, double* tvec, int iterations,

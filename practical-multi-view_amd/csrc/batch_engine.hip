@@ -39,7 +39,8 @@ struct Req {
 struct LKReq : Req {
     int prev_slot, next_slot, n;
     const float* prev_xy; float* out_xy; uint8_t* status; float* err_out;
-    std::vector<int> order;   // XCD-aware block -> track order of THIS request (local indices, -1 = padding), built by the caller
+    uint8_t* iters_out = nullptr;   // optional: LK iterations each track took (the caller's ordering hint for its next request)
+    std::vector<int> order;   // block -> track order of THIS request (local indices, -1 = padding), built by the caller
     int base = 0;             // filled by the combiner: first index in the concatenated arrays
 };
 struct DetReq : Req {
@@ -89,8 +90,8 @@ struct Combiner {
     double t_cpu = 0;                            // CPU seconds of the combiner thread itself
     // LK staging + mapped pinned result blocks; detector buffers (only used by combiners of those classes)
     Growable h_front{nullptr, 0, true}, d_front, h_cells{nullptr, 0, true}, d_cells, d_eig, d_cellmax, d_spill, d_det_xy, d_det_score, d_det_count, h_det{nullptr, 0, true};
-    float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr;
-    float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr;
+    float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr; uint8_t* h_iters = nullptr;
+    float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr; uint8_t* dm_iters = nullptr;
     int* d_flags = nullptr;
     // completion word of the "flag" wait: the last launch of a round is k_signal, which stores the round number into mapped pinned memory
     unsigned* h_done = nullptr; unsigned* dm_done = nullptr; unsigned done_seq = 0;
@@ -125,6 +126,7 @@ struct BatchEngine {
     Queue queue[R_COUNT];
     Combiner comb[R_COUNT][MAX_LANES];
     size_t cap_tracks = 0;
+    bool lk_lpt = true;       // PMV_LK_LPT=0: the round-2 block order (x-sorted stripes per XCD, request after request)
     bool exclusive = false;
     std::mutex exclusive_mu;
     // Pyramids of a batched run are built WHILE the sequences already track (engine_build_begin): round r = frames [r * BUILD_CHUNK,
@@ -238,19 +240,36 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
         int2* hblk = (int2*)(hb + off_blocks);
         float* hxy = (float*)(hb + off_xy);
         int q = 0, bpos = 0;
+        std::vector<LKReq*> live;
         for (LKReq* r : lk) {
             if (r->rc != PMV_OK) continue;
             hseq[q].prev_off = (unsigned long long)r->prev_slot * L.slot_bytes;
             hseq[q].next_off = (unsigned long long)r->next_slot * L.slot_bytes;
-            for (int o : r->order) { hblk[bpos].x = q; hblk[bpos].y = o < 0 ? -1 : r->base + o; bpos++; }
+            if (!E->lk_lpt) for (int o : r->order) { hblk[bpos].x = q; hblk[bpos].y = o < 0 ? -1 : r->base + o; bpos++; }
             memcpy(hxy + (size_t)2 * r->base, r->prev_xy, (size_t)r->n * 8);
+            live.push_back(r);
             q++;
+        }
+        if (E->lk_lpt) {
+            // longest-predicted tracks first, over the WHOLE round: every request's order is "most expensive first" (engine_lk), the
+            // launch takes the k-th track of every request before any (k + 1)-th. Workgroups start in index order, so the tracks that
+            // will iterate longest start first and the launch does not end with one of them started last (a launch ends with its slowest
+            // track: makespan <= work / slots + longest track for an arbitrary order).
+            size_t kmax = 0;
+            for (LKReq* r : live) kmax = std::max(kmax, r->order.size());
+            for (size_t k = 0; k < kmax; k++)
+                for (size_t qi = 0; qi < live.size(); qi++) {
+                    LKReq* r = live[qi];
+                    if (k >= r->order.size()) continue;
+                    const int o = r->order[k];
+                    hblk[bpos].x = (int)qi; hblk[bpos].y = o < 0 ? -1 : r->base + o; bpos++;
+                }
         }
         LKParams P;
         P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f; P.stamps = nullptr; P.counters = ctx->d_lk_counters;
         char* db = C.h_front.dev;   // mapped pinned: every block reads its (sequence, track) record and coordinates once, no copy launch
         EK(launch_lk_batch(s, ctx->d_slots, (const LKSeq*)db, (const int2*)(db + off_blocks), total_blocks, L, (const float*)(db + off_xy), P,
-                           C.dm_out_xy, C.dm_status, C.dm_err));
+                           C.dm_out_xy, C.dm_status, C.dm_err, C.dm_iters));
     }
     SYNC_TIMED(C);
     for (LKReq* r : lk) {
@@ -258,6 +277,7 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
         memcpy(r->out_xy, C.h_out_xy + (size_t)2 * r->base, (size_t)r->n * 8);
         memcpy(r->status, C.h_status + r->base, (size_t)r->n);
         memcpy(r->err_out, C.h_err + r->base, (size_t)r->n * 4);
+        if (r->iters_out) memcpy(r->iters_out, C.h_iters + r->base, (size_t)r->n);
     }
 }
 
@@ -524,6 +544,7 @@ void batch_engine_destroy(pmv_ctx* ctx) {
             if (C.h_out_xy) (void)hipHostFree(C.h_out_xy);
             if (C.h_err) (void)hipHostFree(C.h_err);
             if (C.h_status) (void)hipHostFree(C.h_status);
+            if (C.h_iters) (void)hipHostFree(C.h_iters);
             if (C.d_flags) (void)hipFree(C.d_flags);
         }
     if (E->build_thread.joinable()) E->build_thread.join();
@@ -550,6 +571,7 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
     }
     E->cap_tracks = (size_t)B * ctx->max_tracks;
     if (const char* e = getenv("PMV_BATCH_EXCLUSIVE")) E->exclusive = atoi(e) != 0;
+    if (const char* e = getenv("PMV_LK_LPT")) E->lk_lpt = atoi(e) != 0;
     E->lanes[R_LK] = 2;   // (measured, B = 128: see DESIGN.md §5)
     if (const char* e = getenv("PMV_BATCH_LANES")) for (int& l : E->lanes) l = std::max(1, std::min(MAX_LANES, atoi(e)));
     if (const char* e = getenv("PMV_BATCH_LANES_LK")) E->lanes[R_LK] = std::max(1, std::min(MAX_LANES, atoi(e)));
@@ -576,6 +598,8 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
                 CKC(hipHostMalloc(&C.h_out_xy, E->cap_tracks * 8, hipHostMallocMapped | hipHostMallocCoherent));
                 CKC(hipHostMalloc(&C.h_status, E->cap_tracks, hipHostMallocMapped | hipHostMallocCoherent));
                 CKC(hipHostMalloc(&C.h_err, E->cap_tracks * 4, hipHostMallocMapped | hipHostMallocCoherent));
+                CKC(hipHostMalloc(&C.h_iters, E->cap_tracks, hipHostMallocMapped | hipHostMallocCoherent));
+                CKC(hipHostGetDevicePointer((void**)&C.dm_iters, C.h_iters, 0));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_out_xy, C.h_out_xy, 0));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_status, C.h_status, 0));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_err, C.h_err, 0));
@@ -644,13 +668,24 @@ void batch_engine_stats(BatchEngine* E, long long* counts10, double* times15) {
 }
 
 // ---- request entry points (called from the sequences' own host threads) ---------------------------------------------------------
-int engine_lk(BatchEngine* E, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy, uint8_t* status, float* err) {
+int engine_lk(BatchEngine* E, int prev_slot, int next_slot, const float* prev_xy, int n, float* out_xy, uint8_t* status, float* err,
+              const uint8_t* predicted_iters, uint8_t* iters_out) {
     pmv_ctx* ctx = E->ctx;
     REQ(n >= 0 && n <= ctx->max_tracks, PMV_ERR_CAPACITY, "pmv_lk_track: n=%d exceeds max_tracks=%d", n, ctx->max_tracks);
     REQ(prev_slot >= 0 && prev_slot < ctx->n_slots && next_slot >= 0 && next_slot < ctx->n_slots, PMV_ERR_CAPACITY, "pmv_lk_track: slot out of range");
     if (n == 0) return PMV_OK;
     LKReq r;
     r.kind = 0; r.prev_slot = prev_slot; r.next_slot = next_slot; r.n = n; r.prev_xy = prev_xy; r.out_xy = out_xy; r.status = status; r.err_out = err;
+    r.iters_out = iters_out;
+    if (E->lk_lpt) {
+        // most expensive first: a counting sort on the predicted iteration count (255 .. 0), ties in track order
+        r.order.resize((size_t)n);
+        int cnt[257] = {0};
+        for (int i = 0; i < n; i++) cnt[256 - (predicted_iters ? predicted_iters[i] : 0)]++;   // bucket b = 255 - pred, offset by one for the prefix
+        for (int b = 1; b <= 256; b++) cnt[b] += cnt[b - 1];
+        for (int i = 0; i < n; i++) r.order[(size_t)cnt[255 - (predicted_iters ? predicted_iters[i] : 0)]++] = i;
+        return submit(ctx, E->queue[R_LK], &r);
+    }
     // the same XCD-aware dealing as pmv_lk_track (stripe s of the x-sorted tracks -> blocks 8k + s); a request's block range starts at
     // a multiple of 8 in the concatenated launch, so block % 8 (= XCD) is preserved
     const int nb = (n + 7) / 8 * 8;

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
 constexpr int LKB_T = 64;   // one wavefront per track: throughput form (see block_sum_exact)
 __global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
                                                    int n_blocks, PyrLayout L, const float* __restrict__ prev_xy, LKParams P, float* __restrict__ out_xy,
-                                                   uint8_t* __restrict__ out_status, float* __restrict__ out_err) {
+                                                   uint8_t* __restrict__ out_status, float* __restrict__ out_err, uint8_t* __restrict__ out_iters) {
     // grid-stride over the track list: the launcher may cap the grid (PMV_LK_BATCH_BLOCKS) so that the tracks of a round do not occupy
     // every register-file slot of the chip while the short launches of the back-end chains wait for one
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
@@ -601,6 +601,7 @@ __global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const LKSeq sq = seqs[bt.x];
         const LKResult r = lk_track_block<LKB_T>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, false);
         lk_store(r, bt.y, P, out_xy, out_status, out_err);
+        if (out_iters && threadIdx.x == 0) out_iters[bt.y] = (uint8_t)(r.n_iter > 255 ? 255 : r.n_iter);   // what this track cost: the next launch's ordering hint
         __syncthreads();
     }
 }
@@ -617,12 +618,12 @@ hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* nex
 }
 
 hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_seqs, const int2* d_blocks, int n_blocks, const PyrLayout& L,
-                           const float* d_prev_xy, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err) {
+                           const float* d_prev_xy, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err, uint8_t* d_iters) {
     if (n_blocks <= 0) return hipSuccess;
     if (!slots || !d_seqs || !d_blocks || !d_prev_xy || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     static const int cap = getenv("PMV_LK_BATCH_BLOCKS") ? atoi(getenv("PMV_LK_BATCH_BLOCKS")) : 0;
     ProfScope ps(K_LK, s);
-    hipLaunchKernelGGL(k_lk_batch, dim3(cap > 0 && cap < n_blocks ? cap : n_blocks), dim3(LKB_T), 0, s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err);
+    hipLaunchKernelGGL(k_lk_batch, dim3(cap > 0 && cap < n_blocks ? cap : n_blocks), dim3(LKB_T), 0, s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err, d_iters);
     return hipGetLastError();
 }
 
@@ -725,7 +726,7 @@ __device__ inline void gftt_cov(const uint8_t* __restrict__ p, int st, float& c0
 // seen (0.01 x the cell's maximum, cellinfo[2 cell] by atomicMax). Pass 2 drops the records at or below it. Only values > 0 can ever be
 // selected. HBM traffic: the cell's pixels once (+ halo), 8 B per local maximum - no 4 W H map.
 __global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ slots, PyrLayout L, const int* __restrict__ cells,
-                                                   float* __restrict__ cand_val, unsigned* __restrict__ cand_idx, unsigned* __restrict__ cellinfo) {
+                                                   float* __restrict__ cand_val, unsigned* __restrict__ cand_idx, unsigned* __restrict__ cellinfo, double quality) {
     __shared__ float sC[36 * 36 * 3];
     __shared__ float sE[34 * 34];
     __shared__ unsigned smax[4];
@@ -777,7 +778,14 @@ __global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ s
     }
     // the tile's records are collected in LDS first (sC is free now), then ONE global atomic per workgroup reserves their place in the
     // cell's list (640 workgroups bumping 10 counters per wavefront and turn serialised in L2: 82 us per launch instead of 15)
-    unsigned* s_cnt = smax;                          // [0] tile count, [1] base in the cell's list (smax has been read by thread 0 only)
+    // A record at or below quality x (the largest response seen so far) can be dropped here already: the cell's maximum only grows, the
+    // threshold with it (the same (float)((double)max * quality) as pass 2 uses, monotone in max), so pass 2 would drop it anyway. "So far" =
+    // this tile's own maximum (reading what the other tiles have published - one more global load per thread behind the atomicMax - cost
+    // 15 us per launch, measured): fewer records written, read back and compacted, at no cost.
+    unsigned seen = smax[0];
+    for (int i = 1; i < 4; i++) seen = smax[i] > seen ? smax[i] : seen;
+    const float thr_now = seen ? (float)((double)f32_unkey(seen) * quality) : 0.f;
+    unsigned* s_cnt = smax;                          // [0] tile count, [1] base in the cell's list
     float* lv = sC;                                  // up to 1024 values ...
     unsigned* li = (unsigned*)(sC + 1024);           // ... and pixel indices
     __syncthreads();
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ s
         float v = 0.f;
         if (x >= 1 && y >= 1 && x < cw - 1 && y < ch - 1) {
             v = sE[(oy + 1) * 34 + ox + 1];
-            cand = v > 0.f;
+            cand = v > 0.f && v > thr_now;
 #pragma unroll
             for (int j = 0; j < 3; j++)
 #pragma unroll
@@ -824,6 +832,10 @@ __global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ s
 // one is closer than minDistance") runs as: repeat {arg-max over the live records; accept; kill every record closer than minDistance} -
 // identical result, max_corners rounds of register work with one 4-wavefront exchange each, no sort. A cell with more than GP_REG records
 // above the threshold (a periodic texture can make every pixel a local maximum) takes the same rounds over its list in HBM.
+// Four wavefronts per cell. Measured alternatives (shader-clock stamps, PMV_GFTT_DBG=1; one cell = 2740 raw records, 742 above the threshold):
+// a round is a serial chain (arg-max -> accept -> kill) and costs ~2.9 k cycles whatever the operand width (64-bit keys: 3.4 k) - a lone or
+// nearly lone wavefront issues one DEPENDENT instruction every 10-30 cycles, so the chain's instruction count is what matters; ONE wavefront
+// per cell (no exchange, no barrier, 12 slots per lane) takes 9.6 k cycles per round: the slots' instructions do not overlap, they queue.
 constexpr int GP_T = 256, GP_SLOTS = 16, GP_REG = GP_T * GP_SLOTS, GP_MAXOUT = 4096;   // GP_MAXOUT = MAX_PER_CELL of pmv_ctx.h
 __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cells, float* __restrict__ cand_val, unsigned* __restrict__ cand_idx,
                                                     const unsigned* __restrict__ cellinfo, int max_corners, double quality, double min_dist,
@@ -861,11 +873,13 @@ __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cell
         int wave_tot = 0;
 #pragma unroll
         for (int q = 0; q < CPT; q++) wave_tot += __popcll(__ballot(keep[q]));
-        if (lane == 0) wbest[0][wave] = (unsigned long long)wave_tot;
-        __syncthreads();
-        int off = n;
-        for (int w2 = 0; w2 < wave; w2++) off += (int)wbest[0][w2];
-        const int tot = (int)(wbest[0][0] + wbest[0][1] + wbest[0][2] + wbest[0][3]);
+        int off = n, tot = wave_tot;
+        if (GP_T > 64) {
+            if (lane == 0) wbest[0][wave] = (unsigned long long)wave_tot;
+            __syncthreads();
+            for (int w2 = 0; w2 < wave; w2++) off += (int)wbest[0][w2];
+            tot = (int)(wbest[0][0] + wbest[0][1] + wbest[0][2] + wbest[0][3]);
+        }
         int run = 0;
 #pragma unroll
         for (int q = 0; q < CPT; q++) {
@@ -919,36 +933,45 @@ __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cell
         }
         // arg-max over the workgroup: first the value, then the position among the lanes that hold that value
         const unsigned mv = wave_max_u32(tv);
-        const unsigned mp = wave_max_u32(tv == mv ? tp : 0u);
-        if (lane == 0) { wv[(it & 1) * 4 + wave] = mv; wp[(it & 1) * 4 + wave] = mp; }
-        __syncthreads();   // (one barrier per round: the exchange buffer alternates)
-        const uint4 v4 = *(const uint4*)&wv[(it & 1) * 4], p4 = *(const uint4*)&wp[(it & 1) * 4];
-        const unsigned V = max(max(v4.x, v4.y), max(v4.z, v4.w));
+        // the position: almost always ONE lane holds the maximum value - read its position directly; a second reduction only on a tie
+        const unsigned long long holders = __ballot(tv == mv);
+        unsigned mp;
+        if (__popcll(holders) == 1) mp = (unsigned)__builtin_amdgcn_readlane((int)tp, __builtin_ctzll(holders));
+        else mp = wave_max_u32(tv == mv ? tp : 0u);
+        unsigned V = mv, P = mp;
+        if (GP_T > 64) {   // several wavefronts per cell: one exchange through LDS per round (the buffer alternates)
+            if (lane == 0) { wv[(it & 1) * 4 + wave] = mv; wp[(it & 1) * 4 + wave] = mp; }
+            __syncthreads();
+            const uint4 v4 = *(const uint4*)&wv[(it & 1) * 4], p4 = *(const uint4*)&wp[(it & 1) * 4];
+            V = max(max(v4.x, v4.y), max(v4.z, v4.w));
+            P = max(max(v4.x == V ? p4.x : 0u, v4.y == V ? p4.y : 0u), max(v4.z == V ? p4.z : 0u, v4.w == V ? p4.w : 0u));
+        }
         if (V == 0) break;
-        const unsigned P = max(max(v4.x == V ? p4.x : 0u, v4.y == V ? p4.y : 0u), max(v4.z == V ? p4.z : 0u, v4.w == V ? p4.w : 0u));
         const int bx = (int)(P & 0xffffu), by = (int)(P >> 16);
         if (tid == 0) s_acc[naccepted] = P;
         naccepted++;
         bool died = false;
 #pragma unroll
         for (int s2 = 0; s2 < GP_SLOTS; s2++) {
-            if (s2 >= nslots) break;   // uniform
-            bool kill;
-            if (use_dist) {
-                const int dx = (int)(kp[s2] & 0xffffu) - bx, dy = (int)(kp[s2] >> 16) - by;
-                kill = dx * dx + dy * dy < md2i;
-            } else kill = kp[s2] == P;
-            kill = kill && kv[s2] != 0;
-            if (kill) kv[s2] = 0;
-            died = died || kill;
+            if (s2 < nslots) {   // uniform (no break: the loop has to unroll, the slots are registers)
+                bool kill;
+                if (use_dist) {
+                    const int dx = (int)(kp[s2] & 0xffffu) - bx, dy = (int)(kp[s2] >> 16) - by;
+                    kill = dx * dx + dy * dy < md2i;
+                } else kill = kp[s2] == P;
+                kill = kill && kv[s2] != 0;
+                if (kill) kv[s2] = 0;
+                died = died || kill;
+            }
         }
         if (died) {
             bv = 0; bp = 0;
 #pragma unroll
             for (int s2 = 0; s2 < GP_SLOTS; s2++) {
-                if (s2 >= nslots) break;
-                const bool g = kv[s2] > bv || (kv[s2] == bv && kp[s2] > bp);
-                bv = g ? kv[s2] : bv; bp = g ? kp[s2] : bp;
+                if (s2 < nslots) {
+                    const bool g = kv[s2] > bv || (kv[s2] == bv && kp[s2] > bp);
+                    bv = g ? kv[s2] : bv; bp = g ? kp[s2] : bp;
+                }
             }
         }
         for (int i = GP_REG + tid; i < n; i += GP_T) {
@@ -993,7 +1016,7 @@ hipError_t launch_gftt(hipStream_t s, const uint8_t* slots, const PyrLayout& L, 
     hipError_t e = hipMemsetAsync(d_cellmax, 0, 2 * sizeof(unsigned) * n_cells, s);
     if (e != hipSuccess) return e;
     { ProfScope ps(K_GFTT_CAND, s);
-    hipLaunchKernelGGL(k_gftt_cand, dim3(8, 8, n_cells), dim3(256), 0, s, slots, L, d_cells, d_eig, d_spill, d_cellmax); }
+    hipLaunchKernelGGL(k_gftt_cand, dim3(8, 8, n_cells), dim3(256), 0, s, slots, L, d_cells, d_eig, d_spill, d_cellmax, quality); }
     ProfScope ps2(K_GFTT_PICK, s);
     hipLaunchKernelGGL(k_gftt_pick, dim3(n_cells), dim3(GP_T), 0, s, d_cells, d_eig, d_spill, d_cellmax, max_per_cell,
                        quality, min_dist, unlimited, d_out_xy, d_out_count, d_flags);

@@ -165,9 +165,42 @@ struct BatchShiTomasi : ShiTomasiExtractorBase {
 };
 struct BatchLK : LucasKanadeFMBase {
     pmv_ctx* ctx; pmv::BatchEngine* eng;
+    // Ordering hint for the batched launch (no effect on any result): a track that needed many LK iterations in the last frame pair tends
+    // to need many again (weak texture, an edge along the motion), and a launch ends with its slowest track - so the engine starts the
+    // expensive ones first. The cost of a track is remembered under the integer pixel it was tracked TO, which is where the next call
+    // starts it from (the adapter truncates exactly like this: OpenCVLucasKanadeFM.cpp:25); re-detected features are new: default cost.
+    static constexpr int TBL = 2048, DEFAULT_COST = 24;   // open addressing, > 2 x the tracks of a frame (1024 max)
+    std::vector<uint32_t> tkey = std::vector<uint32_t>(TBL, 0xffffffffu);
+    std::vector<uint8_t> tval = std::vector<uint8_t>(TBL, 0);
+    std::vector<uint8_t> pred, iters;
+    static uint32_t key_of(float x, float y) { return ((uint32_t)(int)y << 16) ^ (uint32_t)(int)x; }
+    static uint32_t slot_of(uint32_t k) { return (k * 2654435761u) >> 21; }   // 11 bits
     void pyrlk(const ImageView& prev, const ImageView& next, const float* prev_xy, int n, float* next_xy, uint8_t* status,
                float* err) override {
-        ck(ctx, pmv::engine_lk(eng, prev.slot, next.slot, prev_xy, n, next_xy, status, err));
+        pred.resize((size_t)n); iters.resize((size_t)n);
+        const bool use = n <= TBL / 2;
+        for (int i = 0; i < n; i++) {
+            uint8_t c = DEFAULT_COST;
+            if (use) {
+                const uint32_t k = key_of(prev_xy[2 * i], prev_xy[2 * i + 1]);
+                for (uint32_t h = slot_of(k);; h = (h + 1) & (TBL - 1)) {
+                    if (tkey[h] == k) { c = tval[h]; break; }
+                    if (tkey[h] == 0xffffffffu) break;
+                }
+            }
+            pred[(size_t)i] = c;
+        }
+        ck(ctx, pmv::engine_lk(eng, prev.slot, next.slot, prev_xy, n, next_xy, status, err, pred.data(), iters.data()));
+        std::fill(tkey.begin(), tkey.end(), 0xffffffffu);
+        if (!use) return;
+        for (int i = 0; i < n; i++) {
+            if (!status[i]) continue;
+            const uint32_t k = key_of(next_xy[2 * i], next_xy[2 * i + 1]);
+            uint32_t h = slot_of(k);
+            while (tkey[h] != 0xffffffffu && tkey[h] != k) h = (h + 1) & (TBL - 1);
+            if (tkey[h] == k) { if (iters[(size_t)i] > tval[h]) tval[h] = iters[(size_t)i]; }   // two tracks on one pixel: the dearer one
+            else { tkey[h] = k; tval[h] = iters[(size_t)i]; }
+        }
     }
 };
 struct BatchPnP : EPnPSolverBase {
