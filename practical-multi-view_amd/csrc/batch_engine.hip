@@ -219,8 +219,11 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     for (LKReq* r : lk) {
         PyrLayout a = ctx->slot_layout[r->prev_slot];
         const PyrLayout& b2 = ctx->slot_layout[r->next_slot];
+        // staged but not built, and not on the background build's list either: there is no pyramid to track on
+        const bool unbuilt = (a.n_levels < 0 && (E->slot_round.empty() || E->slot_round[(size_t)r->prev_slot] < 0)) ||
+                             (b2.n_levels < 0 && (E->slot_round.empty() || E->slot_round[(size_t)r->next_slot] < 0));
         if (a.n_levels < 0) a.n_levels = -a.n_levels;
-        if (a.n_levels == 0 || b2.n_levels == 0 || a.w[0] != b2.w[0] || a.h[0] != b2.h[0]) { r->rc = PMV_ERR_INVALID; snprintf(r->err, sizeof(r->err), "batch LK: slot has no pyramid / sizes differ"); continue; }
+        if (unbuilt || a.n_levels == 0 || b2.n_levels == 0 || a.w[0] != b2.w[0] || a.h[0] != b2.h[0]) { r->rc = PMV_ERR_INVALID; snprintf(r->err, sizeof(r->err), "batch LK: slot has no pyramid / sizes differ"); continue; }
         if (!have_L) { L = a; have_L = true; }
         else if (a.w[0] != L.w[0] || a.h[0] != L.h[0]) { r->rc = PMV_ERR_INVALID; snprintf(r->err, sizeof(r->err), "batch LK: all sequences of a batch must share the frame size"); continue; }
         r->base = total_tracks;
@@ -293,6 +296,9 @@ void process_det(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     std::vector<Group> groups;
     for (DetReq* r : det) {
         PyrLayout Lr = ctx->slot_layout[r->slot];
+        if (Lr.n_levels < 0 && (E->slot_round.empty() || E->slot_round[(size_t)r->slot] < 0)) {
+            r->rc = PMV_ERR_INVALID; snprintf(r->err, sizeof(r->err), "batch detect: slot %d was staged but its pyramid was never built", r->slot); continue;
+        }
         if (Lr.n_levels < 0) Lr.n_levels = -Lr.n_levels;   // staged, its build round is awaited below
         Group* g = nullptr;
         for (Group& x : groups)

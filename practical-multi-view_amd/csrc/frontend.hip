@@ -622,8 +622,15 @@ hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_s
     if (n_blocks <= 0) return hipSuccess;
     if (!slots || !d_seqs || !d_blocks || !d_prev_xy || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     static const int cap = getenv("PMV_LK_BATCH_BLOCKS") ? atoi(getenv("PMV_LK_BATCH_BLOCKS")) : 0;
+    // Occupancy cap of the bulk kernel: 10 KB of LDS per one-wavefront workgroup lets 16 of them fill a CU (160 KB, all four wave slots
+    // of every SIMD at 119 registers), and then every short kernel of the other classes - the 23 launches of an LM solve, the PnP stages,
+    // the detector - waits for LK wavefronts to drain before its workgroups fit anywhere. 12 000 B of unused dynamic LDS on top make it 7
+    // per CU: the LK rounds do not get longer (1555 -> 1601 us at 86 requests with 10 000 B: LK never needed the slots, its wavefronts
+    // mostly wait), the BA rounds drop from 2567 to 1396 us. B = 192, A/B on one box (profiles/r03_batch_exp_k/l/m.log): no cap 49.4 k,
+    // 6 000 B 52.9 k, 10 000 B 52.7 / 54.7 k, 12 500 B 55.7 k, 14 000 B 50.7 k frames/s (22 000 B: 43 k at B = 128). PMV_LK_LDS_PAD overrides (0 = no cap).
+    static const int lds_pad = getenv("PMV_LK_LDS_PAD") ? atoi(getenv("PMV_LK_LDS_PAD")) : 12000;
     ProfScope ps(K_LK, s);
-    hipLaunchKernelGGL(k_lk_batch, dim3(cap > 0 && cap < n_blocks ? cap : n_blocks), dim3(LKB_T), 0, s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err, d_iters);
+    hipLaunchKernelGGL(k_lk_batch, dim3(cap > 0 && cap < n_blocks ? cap : n_blocks), dim3(LKB_T), (size_t)(lds_pad > 0 ? lds_pad : 0), s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err, d_iters);
     return hipGetLastError();
 }
 
