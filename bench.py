@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--poses-out", default="", help="write the estimated poses of the last step in KITTI format")
     ap.add_argument("--batch", type=int, default=192, help="batched leg: B independent sequences through batched launches on each GPU (0 = skip); "
                                                            "192 sequences of the metric config are 234 GB of frame slots (sized for 288 GB of HBM)")
+    ap.add_argument("--batch-ba-mode", type=int, default=0, choices=(0, 1), help="LM implementation of the batched leg (pmv_set_ba_mode): 0 = the launch chain the "
+                    "single-sequence legs use (default; measured faster: 56.2k vs 53.1k frames/s at B=192), 1 = one workgroup per solve, ONE launch per round")
     ap.add_argument("--batch-distinct", type=int, default=16, help="distinct sequences (4 seeds x start offsets) cycled over the B slots of the batched leg")
     ap.add_argument("--batch-contexts", type=int, default=0, help="diagnostic: also run the round-1 form (B contexts x 2 host threads x 2 streams)")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the hbm_resident leg (frames already staged in HBM)")
@@ -364,10 +366,12 @@ def main():
         t_gen_b = time.time() - tg
         # every distinct sequence's own single run (the check of the batched results): through the rank's one-sequence context
         single = []
+        ctx.set_ba_mode(args.batch_ba_mode)   # the single runs the batched results are compared with use the batched leg's LM implementation
         for fr_d, gt_d in distinct:
             ctx.frames_stage(0, fr_d)
             r1 = ctx.pipeline_run(n, w, h, K, gt_d, build_pyramids=1, **dict(run_kw, defer_free=False))
             single.append((r1.poses.copy(), dict(r1.stats)))
+        ctx.set_ba_mode(0)
         ctx.frames_stage(0, data[0][0])
         bc = None
         while bc is None:
@@ -377,6 +381,7 @@ def main():
                 if B <= 8:
                     raise
                 B = B - 32 if B > 64 else B // 2
+        bc.set_ba_mode(args.batch_ba_mode)
         for b in range(B):
             bc.frames_stage(b * n, distinct[b % D][0])   # every slot range holds its own copy (B sequences = B x 1.7 GB of HBM, as real data would)
         bseqs = [(b * n, n, distinct[b % D][1]) for b in range(B)]
@@ -431,6 +436,10 @@ def main():
                               note=f"OPS_lk (measured iterations) of the {lk_round['requests_per_round']} sequences' tracks per launch on average")
             batched = dict(sequences=B, distinct_sequences=D, value=round(tot_frames / max_sec, 3), unit="frames/s", seconds=round(max_sec, 3),
                            n_gpus=world, per_gpu=round(tot_frames / max_sec / world, 3), identical_to_single_run=bool(all_same),
+                           ba_mode=args.batch_ba_mode,
+                           ba_mode_note="pmv_set_ba_mode: 0 = the 23-launch LM chain, problems of a round side by side in each launch; 1 = the whole solve in one "
+                                        "workgroup per problem, one launch per round (slower here: profiles/r03_batch_exp_n.log); the single runs of the "
+                                        "bitwise check use the same mode",
                            distinct_how=f"{n_seed} seeds x start offsets 0/{OFF}/{2 * OFF}/{3 * OFF} frames, cycled over the {B} slot ranges; every batched result "
                                         f"is compared bitwise with the single-sequence run of the same input",
                            host_threads=(2 if bthr else 1) * B + 6, host_cpu_us_per_frame=round(cpu_b / fr_b * 1e6, 1), host_cores_busy=round(cpu_b / dtb, 2),

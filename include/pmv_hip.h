@@ -150,6 +150,13 @@ int pmv_ba_residuals(pmv_ctx* ctx, const double* cams, int nc, const double* pts
                      const int* cam_idx, const int* pt_idx, int n_obs, const double* K, double* out_r,
                      double* out_J);
 /* Levenberg–Marquardt with Huber(huber_delta) loss and Schur elimination of the points; cams/pts updated in place. */
+/* Which of the two LM implementations pmv_ba_solve / the pipeline's BA plugin use on this context (default 0):
+ *   0  the multi-kernel launch chain: every phase of an LM iteration spread over many CUs - the shortest latency for ONE solve;
+ *   1  the whole solve in one workgroup per problem: one launch per solve, and ONE launch per round of B solves in
+ *      pmv_pipeline_run_batch - what a GPU shared by many sequences wants (a launch chain pays for wave slots 23 times).
+ * Same algorithm, same parity bars against the CPU restatement; the floating-point sums are ordered differently, so two runs
+ * are bitwise comparable only under the same mode. */
+int pmv_set_ba_mode(pmv_ctx* ctx, int mode);
 int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx,
                  const int* pt_idx, int n_obs, const double* K, double huber_delta, int max_iterations,
                  pmv_ba_summary* summary);

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "pmv_ctx_create", "pmv_ctx_destroy", "pmv_last_error", "pmv_sync",
     "pmv_frame_upload", "pmv_frame_upload_bgr", "pmv_frames_stage", "pmv_frames_build", "pmv_frames_stream_begin", "pmv_frames_stream_end", "pmv_frame_get_level", "pmv_frame_get_level_padded", "pmv_frame_num_levels",
     "pmv_detect_gftt", "pmv_detect_shitomasi", "pmv_detect_fast", "pmv_knn_match", "pmv_debug_gftt_response", "pmv_debug_shitomasi_response",
-    "pmv_lk_track", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates", "pmv_triangulate_candidates_ahead", "pmv_fivepoint_hypotheses",
+    "pmv_lk_track", "pmv_set_ba_mode", "pmv_pnp_ransac", "pmv_debug_pnp_hypotheses", "pmv_debug_ba_stamps", "pmv_debug_lk_stamps", "pmv_ba_residuals", "pmv_ba_solve", "pmv_triangulate_candidates", "pmv_triangulate_candidates_ahead", "pmv_fivepoint_hypotheses",
     "pmv_record_enable", "pmv_record_count", "pmv_record_size", "pmv_record_get",
     "pmv_prof_enable", "pmv_prof_select", "pmv_prof_kernel_count", "pmv_lk_counters", "pmv_prof_kernel_name", "pmv_prof_read",
     "pmv_pipeline_run", "pmv_pipeline_run_streamed", "pmv_pipeline_run_batch", "pmv_batch_stats", "pmv_pipeline_free", "pmv_pipeline_release", "pmv_pipeline_drain", "pmv_pipeline_num_poses", "pmv_pipeline_get_poses", "pmv_pipeline_num_frames",
@@ -372,6 +372,10 @@ class Context:
                                            _p(obs, _f64p), _p(ci, _i32p), _p(pi, _i32p), n, _p(Kd, _f64p),
                                            _p(r, _f64p), _p(J, _f64p)))
         return r, J
+
+    def set_ba_mode(self, mode):
+        """0 = multi-kernel LM chain (default), 1 = one workgroup per solve / one launch per batched round"""
+        self._ck(self.lib.pmv_set_ba_mode(self.h, int(mode)))
 
     def ba_solve(self, cams, pts, obs_xy, cam_idx, pt_idx, K, huber=1.0, max_iterations=5):
         cams = np.array(cams, np.float64).reshape(-1, 6).copy()

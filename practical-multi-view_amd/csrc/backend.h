@@ -84,6 +84,8 @@ struct BABatchDims { int n_probs, max_eval_blocks, max_nc, max_nbp, max_tiles, m
 // fills everything of `P` that launch_ba_multi computes from A / d_state / d_part (host side; the result is copied to the device)
 void ba_fill_prob(BAProb& P, const BAArgs& A, void* d_state, double* d_part);
 hipError_t launch_ba_multi_batch(hipStream_t s, const BAProb* d_probs, const BABatchDims& D);
+// the one-workgroup-per-problem form (pmv_set_ba_mode(ctx, 1)): d_args[i] = problem i, max_m = largest 6 * nc of the batch
+hipError_t launch_ba_lm_batch(hipStream_t s, const BAArgs* d_args, int n_probs, int max_m);
 // one RANSAC problem of a batched PnP launch (device pointers)
 struct PnPProblem {
     const float* obj; const float* img; const int* samples; const double* K;   // K: 9 doubles + 10^k table (see pmv_pnp_ransac)

@@ -437,6 +437,12 @@ void pmv::ba_finish(pmv_ctx* ctx, BackendBuffers* b, double* cams, int nc, doubl
 
 extern "C" {
 
+int pmv_set_ba_mode(pmv_ctx* ctx, int mode) {
+    if (!ctx || (mode != 0 && mode != 1)) { set_err(ctx, "pmv_set_ba_mode: mode must be 0 (launch chain) or 1 (one workgroup per solve)"); return PMV_ERR_INVALID; }
+    ctx->ba_mode = mode;
+    return PMV_OK;
+}
+
 int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const double* obs_xy, const int* cam_idx, const int* pt_idx,
                  int n_obs, const double* K, double huber_delta, int max_iterations, pmv_ba_summary* summary) {
     int rc = ba_check(ctx, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber_delta, max_iterations);
@@ -452,7 +458,7 @@ int pmv_ba_solve(pmv_ctx* ctx, double* cams, int nc, double* pts, int np, const 
     // launch mode: multi (one launch per LM phase, default) | single (one persistent workgroup); PMV_BA_MODE overrides
     static const int mode = [] { const char* e = getenv("PMV_BA_MODE"); if (getenv("PMV_BA_SINGLE")) return 0;
                                  return (e && !strcmp(e, "single")) ? 0 : 1; }();
-    const bool single = mode == 0;
+    const bool single = mode == 0 || ctx->ba_mode == 1;
     BAArgs A;
     size_t io_bytes = 0;
     rc = ba_prepare(ctx, b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber_delta, max_iterations, !single, &A, &io_bytes);

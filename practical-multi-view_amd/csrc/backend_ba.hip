@@ -273,7 +273,10 @@ __device__ inline v4d cam_block_mfma(const double* __restrict__ J, const double*
     return acc;   // D[row = (lane>>4) + 4*reg][col = lane&15]
 }
 
-__global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) { BACKEND_PRIO();
+// The whole LM solve of ONE problem in one 512-thread workgroup (round 1's kernel; see the multi-kernel chain below for why one sequence uses
+// the chain). Batched form k_ba_lm_batch: blockIdx.x = problem - ONE launch per round of B sequences instead of 23, which is what the batched
+// leg wants (in the mix a launch costs 60-90 us of waiting for wave slots, pmv_set_ba_mode).
+__device__ __forceinline__ void ba_lm_body(const BAArgs& A) {
     __shared__ double red[BA_NW];
     __shared__ BAState st;
     __shared__ CamRot crot[32];
@@ -741,6 +744,18 @@ __global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) { BACKEND_PRIO();
     if (A.stamps && tid == 0) { A.stamps[28] = wall_clock64() - A.stamps[30]; A.stamps[29] = __builtin_readcyclecounter() - A.stamps[31]; }
     if (tid == 0) {
         A.summary[1] = st.x_cost; A.summary[2] = st.iter; A.summary[3] = st.successful; A.summary[4] = st.termination;
+    }
+}
+__global__ __launch_bounds__(BA_T) void k_ba_lm(BAArgs A) { BACKEND_PRIO(); ba_lm_body(A); }
+// args[blockIdx.x] = one problem; when A.out is set (mapped pinned result block: [summary 8 | cams | pts]) the result is copied there
+__global__ __launch_bounds__(BA_T) void k_ba_lm_batch(const BAArgs* __restrict__ args) { BACKEND_PRIO();
+    const BAArgs A = args[blockIdx.x];
+    ba_lm_body(A);
+    if (A.out) {
+        __syncthreads();   // (the body's last stores to A.cams / A.pts / A.summary: same workgroup)
+        const int nsum = 8, ncam = 6 * A.nc, npt = 3 * A.np;
+        for (int i = threadIdx.x; i < nsum + ncam + npt; i += BA_T)
+            A.out[i] = i < nsum ? A.summary[i] : (i < nsum + ncam ? A.cams[i - nsum] : A.pts[i - nsum - ncam]);
     }
 }
 
@@ -1668,6 +1683,13 @@ hipError_t launch_ba_residuals(hipStream_t s, const double* cams, const double* 
     hipLaunchKernelGGL(k_ba_residuals, dim3((nobs + 255) / 256), dim3(256), 0, s, cams, pts, obs, cam_idx, pt_idx, nobs, K, out_r, out_J);
     return hipGetLastError();
 }
+hipError_t launch_ba_lm_batch(hipStream_t s, const BAArgs* d_args, int n_probs, int max_m) {
+    if (!d_args || n_probs < 1 || max_m < 6) return hipErrorInvalidValue;
+    const size_t shm = ((size_t)(max_m + 1) * max_m + (size_t)max_m) * sizeof(double);
+    ProfScope ps(K_BA_LM, s);
+    hipLaunchKernelGGL(k_ba_lm_batch, dim3(n_probs), dim3(BA_T), shm, s, d_args);
+    return hipGetLastError();
+}
 hipError_t launch_ba_lm(hipStream_t s, const BAArgs& A) {
     const int m = 6 * A.nc;
     const size_t shm = ((size_t)(m + 1) * m + (size_t)m) * sizeof(double);   // [S | rhs row] + camera step, LDS-resident
@@ -1681,6 +1703,8 @@ hipError_t backend_prepare_device() {
     hipError_t e = hipFuncSetAttribute((const void*)k_bam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_bamB_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_ba_lm_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }

@@ -269,7 +269,14 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
                 }
         }
         LKParams P;
-        P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f; P.stamps = nullptr; P.counters = ctx->d_lk_counters;
+        P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f; P.counters = ctx->d_lk_counters;
+        static const bool lk_stamps = getenv("PMV_LK_STAMPS") != nullptr;   // diagnostic: phase timers of every 64th track (pmv_debug_lk_stamps)
+        if (lk_stamps) {
+            static std::mutex stamps_mu;   // two LK lanes
+            std::lock_guard<std::mutex> lk_(stamps_mu);
+            if (!ctx->d_lk_stamps && hipMalloc(&ctx->d_lk_stamps, 16 * 8) == hipSuccess) (void)hipMemset(ctx->d_lk_stamps, 0, 16 * 8);
+        }
+        P.stamps = lk_stamps ? ctx->d_lk_stamps : nullptr;
         char* db = C.h_front.dev;   // mapped pinned: every block reads its (sequence, track) record and coordinates once, no copy launch
         EK(launch_lk_batch(s, ctx->d_slots, (const LKSeq*)db, (const int2*)(db + off_blocks), total_blocks, L, (const float*)(db + off_xy), P,
                            C.dm_out_xy, C.dm_status, C.dm_err, C.dm_iters));
@@ -412,6 +419,21 @@ void process_pnp(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
 }
 
 void process_ba(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
+    if (E->ctx->ba_mode == 1) {   // one workgroup per problem: ONE launch for the whole round (pmv_set_ba_mode)
+        DescBlock<BAArgs> D;
+        EK(desc_block(C, batch.size(), D));
+        int max_m = 6;
+        for (size_t i = 0; i < batch.size(); i++) {
+            BAReq* r = (BAReq*)batch[i];
+            D.hprob[i] = r->A;
+            D.hjobs[i] = StageJob{(const char*)r->b->d_h_stage, r->b->d_ba_io, (unsigned)r->io_bytes, 0};
+            max_m = std::max(max_m, 6 * r->A.nc);
+        }
+        EK(stage_in(C, D, batch.size(), 8));
+        EK(launch_ba_lm_batch(C.s, D.dprob, (int)batch.size(), max_m));
+        SYNC_TIMED(C);
+        return;
+    }
     // one launch chain per distinct iteration cap (in practice one)
     std::vector<int> iters;
     for (Req* q : batch) { const int it = ((BAReq*)q)->max_iterations; if (std::find(iters.begin(), iters.end(), it) == iters.end()) iters.push_back(it); }
@@ -748,8 +770,9 @@ int engine_ba(BatchEngine* E, int seq, double* cams, int nc, double* pts, int np
     if (max_iterations == 0) return PMV_OK;
     BAReq r;
     r.kind = 11; r.b = E->slots[seq]; r.max_iterations = max_iterations;
-    rc = ba_prepare(ctx, r.b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, true, &r.A, &r.io_bytes);
+    rc = ba_prepare(ctx, r.b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, ctx->ba_mode != 1, &r.A, &r.io_bytes);
     if (rc) return rc;
+    if (ctx->ba_mode == 1) r.A.out = (double*)r.b->d_h_stage;   // k_ba_lm_batch copies [summary | cams | pts] into the request's pinned block
     rc = submit(ctx, E->queue[R_BA], &r);
     if (rc) return rc;
     ba_finish(ctx, r.b, cams, nc, pts, np, obs_xy, cam_idx, pt_idx, n_obs, K, huber, max_iterations, nullptr);

@@ -347,7 +347,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
     int n_iter = 0, n_lev = 0;   // work counters for the roofline's measured OPS_lk
     const int ml = L.n_levels - 1;
     unsigned long long t_prev = __builtin_readcyclecounter();
-#define LSTAMP(k) do { if (P.stamps && stamp_on && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); P.stamps[k] += t_ - t_prev; t_prev = t_; } } while (0)
+#define LSTAMP(k) do { if (P.stamps && stamp_on && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&P.stamps[k], t_ - t_prev); t_prev = t_; } } while (0)
 
     for (int level = ml; level >= 0; level--) {
         LSTAMP(0);
@@ -514,7 +514,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             nx += dx; ny += dy;
             outx = nx + half; outy = ny + half;
             n_iter++;
-            if (P.stamps && stamp_on && tid == 0) P.stamps[8] += 1;
+            if (P.stamps && stamp_on && tid == 0) atomicAdd(&P.stamps[8], 1ull);
             if ((double)dx * dx + (double)dy * dy <= P.eps2d) break;
             if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
@@ -599,7 +599,8 @@ __global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const int2 bt = blocks[b];
         if (bt.y < 0) continue;
         const LKSeq sq = seqs[bt.x];
-        const LKResult r = lk_track_block<LKB_T>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, false);
+        const LKResult r = lk_track_block<LKB_T>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, P.stamps && (b & 63) == 17);
+        if (P.stamps && (b & 63) == 17 && threadIdx.x == 0) atomicAdd(&P.stamps[13], 1ull);   // diagnostic: sampled tracks
         lk_store(r, bt.y, P, out_xy, out_status, out_err);
         if (out_iters && threadIdx.x == 0) out_iters[bt.y] = (uint8_t)(r.n_iter > 255 ? 255 : r.n_iter);   // what this track cost: the next launch's ordering hint
         __syncthreads();

@@ -60,6 +60,11 @@ struct pmv_ctx {
     pmv::BackendBuffers* be_ahead = nullptr;
     hipStream_t s_ahead = nullptr;
     std::mutex ahead_mu;
+    // pmv_set_ba_mode: 0 = the multi-kernel LM chain (shortest latency for ONE solve: every phase spread over many CUs),
+    // 1 = the whole solve in one workgroup per problem (k_ba_lm / k_ba_lm_batch: ONE launch per solve or per round of B solves).
+    // Both are checked against the oracle to the same bars; their floating-point sums are ordered differently, so runs are compared
+    // bit for bit only within one mode.
+    int ba_mode = 0;
     pmv::BatchEngine* engine = nullptr; // created by the first pmv_pipeline_run_batch
     pmv::Ingest* ingest = nullptr;      // non-null while a pmv_frames_stream_begin .. _end bracket is open
     pmv::Profiler prof;

@@ -18,6 +18,8 @@ Bmax = max(Bs)
 ctx = pmv.Context(cfg["w"], cfg["h"], n_slots=Bmax * n, max_tracks=1024, max_ba_cams=8, max_ba_points=2048, max_ba_obs=16384)
 for b in range(Bmax):
     ctx.frames_stage(b * n, frames)
+if os.environ.get("BA_MODE"):
+    ctx.set_ba_mode(int(os.environ["BA_MODE"]))   # 1: one workgroup per solve, one launch per batched BA round
 ref = None
 THREADED = int(os.environ.get("THREADED", "1"))
 DEVFP = int(os.environ.get("DEVFP", "0"))
@@ -40,11 +42,21 @@ for B in Bs:
         ref = r2[0].poses
     same = all(np.array_equal(x.poses, ref) for x in r2)
     print(f"B={B:3d}: {fr / dt:9.1f} frames/s  ({dt:.3f} s)  identical={same}  process CPU {cpu:.2f} s = {cpu / fr * 1e6:.0f} us per frame, {cpu / dt:.1f} cores busy", flush=True)
+    keys = [k for k in ("t_lk", "t_detect", "t_pnp", "t_tri", "t_ba", "t_tri_essential", "t_tri_pose", "tri_hypotheses", "tri_ahead") if k in r2[0].stats]
+    print("        per frame (wall of the calling threads, us):", {k: round(sum(float(x.stats[k]) for x in r2) / fr * (1.0 if k.startswith("tri_") else 1e6), 2) for k in keys}, flush=True)
     for role in s1:
         d = {k: s1[role][k] - s0[role][k] for k in s1[role]}
         if d["launches"]:
             print(f"        {role:4s} {d['requests'] / d['launches']:5.1f} req/launch, {d['launches']:5d} launches, cpu {d['cpu_s']:.2f} s, work {d['work_s']:.2f} s (sync {d['sync_s']:.2f} s)"
                   f"  -> {d['work_s'] / d['launches'] * 1e6:.0f} us per round", flush=True)
+    if os.environ.get("PMV_LK_STAMPS"):   # phase timers of every 64th track of the batched LK launches (shader cycles)
+        import ctypes as C
+        out = np.zeros(16, np.uint64)
+        ctx.lib.pmv_debug_lk_stamps(ctx.h, out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        nt, it = max(1, int(out[13])), max(1, int(out[8]))
+        names = ["level-entry", "I-tile", "scharr", "samples+A", "iterations(+J tiles)", "err-pass"]
+        print("        LK stamps:", nt, "sampled tracks; cycles per track:", " ".join("%s=%d" % (nm, int(out[i]) / nt) for i, nm in enumerate(names)), "iterations/track %.1f" % (it / nt))
+        print("        per iteration: top(tile check / J stage)=%d sample+diff=%d wave-sum=%d update=%d cycles" % tuple(int(out[k]) / it for k in (9, 10, 11, 12)), flush=True)
     for x in r + r2:
         x.free()
 ctx.close()

@@ -193,6 +193,30 @@ def test_ba_single_workgroup_variant_agrees(gpu_ctx_factory):
     np.testing.assert_allclose(np.array(r["pts"]), pts, rtol=1e-6, atol=1e-6)
 
 
+def test_ba_mode_one_workgroup_matches_oracle_and_default(gpu_ctx_factory):
+    """pmv_set_ba_mode(ctx, 1): the whole LM loop of a call in ONE workgroup (k_ba_lm; the batched engine's k_ba_lm_batch runs the
+    same body per problem). Same oracle bars as the default chain of launches, switchable per context and back."""
+    P = scenes.ba_problem(23, nc=5, npts=400)
+    ctx = _ctx(gpu_ctx_factory)
+    rc, rp, rs = ob.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 5)
+    d_cams, d_pts, d_s = ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 5)
+    ctx.set_ba_mode(1)
+    cams, pts, s = ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 5)
+    again = ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 5)
+    assert np.array_equal(cams, again[0]) and np.array_equal(pts, again[1]), "mode 1 is not bitwise reproducible"
+    assert s.iterations == rs["iterations"] and s.successful_steps == rs["successful_steps"] and s.termination == rs["termination"]
+    np.testing.assert_allclose(s.initial_cost, rs["initial_cost"], rtol=1e-12)
+    np.testing.assert_allclose(s.final_cost, rs["final_cost"], rtol=1e-8)
+    np.testing.assert_allclose(cams, rc, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pts, rp, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(cams, d_cams, rtol=1e-6, atol=1e-8)
+    ctx.set_ba_mode(0)
+    back = ctx.ba_solve(P["cams"], P["pts"], P["obs"], P["cam_idx"], P["pt_idx"], scenes.K, 1.0, 5)
+    assert np.array_equal(back[0], d_cams) and np.array_equal(back[1], d_pts), "switching back does not restore the default path"
+    with pytest.raises(Exception):
+        ctx.set_ba_mode(7)
+
+
 def test_fivepoint_round_on_device_is_bit_exact(pmv, orc, gpu_ctx_factory):
     """the hypothesis half of cv::findEssentialMat on the GPU (k_fivepoint_hyp: Nister's solver, one thread per sample;
     k_fivepoint_score: float32 Sampson inlier counts) against the host solver that the CPU known-answer tests pin

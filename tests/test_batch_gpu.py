@@ -54,6 +54,35 @@ def test_batch_of_different_sequences_equals_single_runs(pmv, gpu_ctx_factory):
         _assert_same(r, got[b], f"re-run of sequence {b}")
 
 
+def test_batch_with_one_workgroup_ba_equals_single_runs_in_that_mode(pmv, gpu_ctx_factory):
+    """pmv_set_ba_mode(1): the BA combiner solves every problem of a round in one launch (k_ba_lm_batch, one workgroup per problem);
+    a sequence's results equal its own run with the same mode, bit for bit, and stay within the BA bar of the default mode."""
+    cfg = K00
+    lengths = [48, 37, 55, 48]
+    seeds = [1000, 1001, 1002, 1000]
+    K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=sum(lengths), max_tracks=4096)
+    ctx.set_ba_mode(1)
+    seqs, data = _stage(pmv, ctx, cfg, lengths, seeds)
+    got = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K)
+    st = ctx.batch_stats()
+    assert st["ba"]["requests"] > st["ba"]["launches"] > 0
+    single = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=max(lengths), max_tracks=4096)
+    single.set_ba_mode(1)
+    for b, (frames, gt) in enumerate(data):
+        single.frames_stage(0, frames)
+        ref = single.pipeline_run(lengths[b], cfg["w"], cfg["h"], K, gt, threaded=1)
+        _assert_same(got[b], ref, f"sequence {b} (BA mode 1)")
+    _assert_same(got[0], got[3], "same input in two batch slots")
+    single.set_ba_mode(0)
+    single.frames_stage(0, data[1][0])
+    ref0 = single.pipeline_run(lengths[1], cfg["w"], cfg["h"], K, data[1][1], threaded=1)
+    # the two BA forms differ in summation order only: the trajectories agree far below the drift of the method
+    d = np.abs(np.asarray(got[1].poses) - np.asarray(ref0.poses)).max()
+    print("largest pose difference between the two BA forms over", lengths[1], "frames:", d)
+    assert d < 1e-2
+
+
 def test_batch_other_configurations(pmv, gpu_ctx_factory):
     """ShiTomasi extractor, and 800 tracks / bundle 10 (60x60 reduced camera system): batched == single"""
     cfg = K00
