@@ -249,29 +249,51 @@ __device__ inline void bilinear_weights(float a, float b, int& w00, int& w01, in
     w11 = 16384 - w00 - w01 - w10;
 }
 
-// Block-wide EXACT sums of per-thread int32 partials (4 wavefronts). The partials are converted to double: every partial sum of
-// these integers stays far below 2^53 (<= 1024 pixels x 8160 x 4080 = 3.4e10), so double addition is exact in any order — one
-// DPP reduction per value instead of the hi/lo int32 pair. Each wavefront leaves its total in LDS and after ONE barrier every
-// thread adds the four totals. `slot` alternates between calls that are not separated by another barrier (iteration parity),
+// Block-wide EXACT sums of per-thread int32 partials (4 wavefronts). A wavefront's total leaves wave_sum_i32_exact as a double: every
+// sum of these integers stays far below 2^53 (<= 1024 pixels x 8160 x 4080 = 3.4e10), so double addition is exact in any order.
+// Each wavefront leaves its total in LDS and after ONE barrier every thread adds the four totals. `slot` alternates between calls that are not separated by another barrier (iteration parity),
 // so the next write never overtakes a pending read. (float)(total) rounds the exact integer once, like (float)(int64).
 // T = threads per track: 256 (four wavefronts: the shortest chain per track, used when one sequence's ~300 tracks are all there is)
 // or 64 (one wavefront: no barrier in the reduction and four times as many tracks resident per CU — the throughput form used by the
 // batched launch, where thousands of tracks are in flight). Integer sums are exact, so both give the same bits.
 constexpr int LK_T = 256;
+// One wavefront's exact sum of int32 partials as a double: the partial is split into its low 16 bits (unsigned) and the rest (signed),
+// each half summed with six DPP steps folded into v_add_u32 and read from lane 63 (no half can overflow: 64 x 65535 and
+// 64 x 2^15), total = 65536 * H + L, exact in double. The double-precision DPP form this replaces cost 23 dependent vector instructions
+// per value (1.4 k clk per LK iteration for two values: a fifth of a track's time in the batched launch).
+// The halves of all N values go through each step TOGETHER: 2N independent instructions per step fill the wait states a DPP or swap
+// result needs before its next use (one chain after the other spent more slots on s_nop than on adds).
+template <int N>
+__device__ __forceinline__ void wave_sum_i32_exact(const int (&part)[N], double (&out)[N]) {
+    int h[2 * N];
+#pragma unroll
+    for (int k = 0; k < N; k++) { h[2 * k] = part[k] & 0xffff; h[2 * k + 1] = part[k] >> 16; }
+#pragma unroll
+    for (int k = 0; k < 2 * N; k++) h[k] += __builtin_amdgcn_update_dpp(0, h[k], 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int k = 0; k < 2 * N; k++) h[k] += __builtin_amdgcn_update_dpp(0, h[k], 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int k = 0; k < 2 * N; k++) h[k] += __builtin_amdgcn_update_dpp(0, h[k], 0x141, 0xf, 0xf, false);   // row_half_mirror
+#pragma unroll
+    for (int k = 0; k < 2 * N; k++) h[k] += __builtin_amdgcn_update_dpp(0, h[k], 0x140, 0xf, 0xf, false);   // row_mirror: the 16-lane row's sum in every lane
+    // across the four rows: lane 15 of a row into the next row (rows 1 and 3), then lane 31 into rows 2 and 3 - lane 63 holds the total
+#pragma unroll
+    for (int k = 0; k < 2 * N; k++) h[k] += __builtin_amdgcn_update_dpp(0, h[k], 0x142, 0xa, 0xf, false);   // row_bcast:15
+#pragma unroll
+    for (int k = 0; k < 2 * N; k++) h[k] += __builtin_amdgcn_update_dpp(0, h[k], 0x143, 0xc, 0xf, false);   // row_bcast:31
+#pragma unroll
+    for (int k = 0; k < N; k++) out[k] = (double)__builtin_amdgcn_readlane(h[2 * k + 1], 63) * 65536.0 + (double)__builtin_amdgcn_readlane(h[2 * k], 63);
+}
 template <int N, int T>
 __device__ inline void block_sum_exact(const int (&part)[N], double (&out)[N], double* sred /* [2][T/64][4] */, int slot) {
     constexpr int NW = T / 64;
-    if (NW == 1) {
-#pragma unroll
-        for (int k = 0; k < N; k++) out[k] = wave_sum_f64((double)part[k]);
-        return;
-    }
+    if (NW == 1) { wave_sum_i32_exact<N>(part, out); return; }
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double v[N];
+    wave_sum_i32_exact<N>(part, v);
 #pragma unroll
-    for (int k = 0; k < N; k++) {
-        const double v = wave_sum_f64((double)part[k]);
-        if (lane == 0) sred[(slot * NW + wv) * 4 + k] = v;
-    }
+    for (int k = 0; k < N; k++)
+        if (lane == 0) sred[(slot * NW + wv) * 4 + k] = v[k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -309,14 +331,34 @@ __device__ inline uint32_t pack_weights(int lo, int hi) { return ((uint32_t)lo &
 #define PACKED_COLUMN(top, bot, k) __builtin_amdgcn_perm((bot)[(k) >> 2], (top)[(k) >> 2], 0x0c040c00u | ((uint32_t)((k) & 3) << 16) | (uint32_t)((k) & 3))
 __device__ inline int dot2_acc(uint32_t a, uint32_t w, int acc) { return __builtin_amdgcn_sdot2(as_s16x2(a), as_s16x2(w), acc, false); }
 
-// 64x64-byte search tile, dword copies (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0): 1024 dwords over T threads
+// 64x64-byte search tile (stride % 64 == 0, PAD % 4 == 0, tx0 % 4 == 0) in two halves: `tile_issue` starts the global loads (16 bytes
+// per lane and load, 256 / T of them) into registers, `tile_commit` writes them to LDS. The caller puts independent work between the
+// two - the iterations of the level above - so that the round trip to HBM (7 us per tile in a batched launch, a third of a track's
+// time when it was waited for in place) overlaps it.
+struct __attribute__((packed, aligned(4))) U4A { uint32_t x, y, z, w; };   // 16 bytes at a 4-byte-aligned address: one global_load_dwordx4
+struct __attribute__((packed, aligned(4))) U2A { uint32_t x, y; };
+template <int T>
+__device__ __forceinline__ void tile_issue(U4A (&reg)[256 / T], const uint8_t* Jorg, int js, int tx0, int ty0, int tid) {
+#pragma unroll
+    for (int q = 0; q < 256 / T; q++) {
+        const int idx = tid + q * T, row = idx >> 2, x4 = idx & 3;
+        reg[q] = *(const U4A*)(Jorg + (ptrdiff_t)(ty0 + row) * js + tx0 + 16 * x4);
+    }
+}
+template <int T>
+__device__ __forceinline__ void tile_commit(uint8_t* sJ, const U4A (&reg)[256 / T], int tid) {
+#pragma unroll
+    for (int q = 0; q < 256 / T; q++) {
+        const int idx = tid + q * T, row = idx >> 2, x4 = idx & 3;
+        uint32_t* d = (uint32_t*)(sJ + row * SJ_STRIDE) + 4 * x4;
+        d[0] = reg[q].x; d[1] = reg[q].y; d[2] = reg[q].z; d[3] = reg[q].w;
+    }
+}
 template <int T>
 __device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0, int ty0, int tid) {
-#pragma unroll
-    for (int q = 0; q < 1024 / T; q++) {
-        const int idx = tid + q * T, row = idx >> 4, xw = idx & 15;
-        ((uint32_t*)(sJ + row * SJ_STRIDE))[xw] = *(const uint32_t*)(Jorg + (ptrdiff_t)(ty0 + row) * js + tx0 + 4 * xw);
-    }
+    U4A reg[256 / T];
+    tile_issue<T>(reg, Jorg, js, tx0, ty0, tid);
+    tile_commit<T>(sJ, reg, tid);
 }
 
 // One 256-thread block (4 wavefronts) per track: thread = window row (tid >> 3) and 4 consecutive columns ((tid & 7) * 4); its
@@ -326,14 +368,17 @@ __device__ inline void stage_J(uint8_t* sJ, const uint8_t* Jorg, int js, int tx0
 // One track through all pyramid levels; executed by one whole 256-thread block (every thread gets the same results). `stamp_on`:
 // this block feeds the diagnostic phase timers.
 struct LKResult { float x, y, err; int status, n_iter, n_lev; };
-template <int T>
+template <int T, bool STAMPS>
 __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS, const PyrLayout& L,
                                                    const float px0, const float py0, const LKParams& P, const bool stamp_on) {
-    __shared__ __attribute__((aligned(16))) uint8_t sI[35 * SI_STRIDE + 4];   // + one dword: the aligned loads of the last row may touch it
+    constexpr int NPRE = 4;                       // I tiles staged per group (all levels of a 4-level pyramid at once)
+    constexpr int SI_BYTES = 35 * SI_STRIDE + 8;   // + two dwords: the aligned loads of the last row may touch the first
+    __shared__ __attribute__((aligned(16))) uint8_t sIall[NPRE * SI_BYTES];
     __shared__ __attribute__((aligned(16))) short2 sD[33 * SD_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t sJ[64 * SJ_STRIDE];
     __shared__ double sred[2 * (T / 64) * 4];
     constexpr int TPR = T / 32, PP = 32 / TPR;   // threads per window row, pixels per thread (256 -> 8 x 4, 64 -> 2 x 16)
+    constexpr int NIQ = (35 * 5 + T - 1) / T;     // 8-byte loads per thread of one I tile (35 rows x 40 bytes)
     const int tid = threadIdx.x;
     // 32 consecutive lanes = the 32 window rows of one column group: their LDS rows differ, and with the odd dword strides of sJ (17)
     // and sD (33) they fall into 32 different banks (the sums are exact integers, so the pixel-to-lane assignment is free)
@@ -347,37 +392,87 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
     int n_iter = 0, n_lev = 0;   // work counters for the roofline's measured OPS_lk
     const int ml = L.n_levels - 1;
     unsigned long long t_prev = __builtin_readcyclecounter();
-#define LSTAMP(k) do { if (P.stamps && stamp_on && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&P.stamps[k], t_ - t_prev); t_prev = t_; } } while (0)
+    const unsigned long long wall0 = (STAMPS && P.stamps && stamp_on) ? wall_clock64() : 0ull;   // 100 MHz: calibrates the cycle counter of the stamps
+#define LSTAMP(k) do { if (STAMPS && P.stamps && stamp_on && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&P.stamps[k], t_ - t_prev); t_prev = t_; } } while (0)
+
+    // where the template window of a level sits: known for every level before anything is tracked (only the search side depends on the
+    // level above), so the I tiles of all levels are fetched at once - one round trip to memory instead of one per level
+    auto template_origin = [&](int level, float& fx, float& fy, int& ipx, int& ipy) -> bool {
+        const float lscale = __int_as_float((127 - level) << 23);   // 2^-level, the value of (float)(1. / (1 << level))
+        fx = px0 * lscale - half; fy = py0 * lscale - half;
+        ipx = (int)floorf(fx); ipy = (int)floorf(fy);
+        return !(ipx < -W || ipx >= L.w[level] || ipy < -W || ipy >= L.h[level]);
+    };
+    // 35x35 I tiles (rows ipy-1 .. ipy+33, cols ipx-1 .. ipx+33, always inside the padded buffer) of levels top .. top-3 as 8-byte copies
+    // of 40-byte rows that start at the 4-byte-aligned column below ipx-1 (35 + 3 <= 40 columns stay inside the 64-pixel frame)
+    int tx0 = 0, ty0 = 0, tile_level = -1;   // the search tile in sJ: origin and the level it was cut from
+    auto stage_I_group = [&](int top, bool with_search_tile) {
+        U2A ireg[NPRE][NIQ];
+        U4A jreg[256 / T];
+        bool j_ok = false;
+#pragma unroll
+        for (int g = 0; g < NPRE; g++) {
+            const int lv = top - g;
+            float fx, fy; int ipx, ipy;
+            if (lv < 0 || !template_origin(lv, fx, fy, ipx, ipy)) continue;   // block-uniform
+            const uint8_t* Iorg = level_origin(prevS, L, lv);
+            const int ls = L.stride[lv], ax0 = (ipx - 1) & ~3;
+#pragma unroll
+            for (int q = 0; q < NIQ; q++) {
+                const int idx = tid + q * T, y = idx / 5, xw = idx - y * 5;
+                if (idx < 35 * 5) ireg[g][q] = *(const U2A*)(Iorg + (ptrdiff_t)(ipy - 1 + y) * ls + ax0 + 8 * xw);
+            }
+        }
+        if (with_search_tile) {   // the top level's search starts at the template position: its tile rides along
+            float fx, fy; int inx, iny;
+            if (template_origin(top, fx, fy, inx, iny)) {
+                tx0 = (inx - 16) & ~3; ty0 = iny - 16;
+                tile_issue<T>(jreg, level_origin(nextS, L, top), L.stride[top], tx0, ty0, tid);
+                j_ok = true;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NPRE; g++) {
+            const int lv = top - g;
+            float fx, fy; int ipx, ipy;
+            if (lv < 0 || !template_origin(lv, fx, fy, ipx, ipy)) continue;
+            uint8_t* dst = sIall + (lv & (NPRE - 1)) * SI_BYTES;
+#pragma unroll
+            for (int q = 0; q < NIQ; q++) {
+                const int idx = tid + q * T, y = idx / 5, xw = idx - y * 5;
+                if (idx < 35 * 5) { uint32_t* d = (uint32_t*)(dst + y * SI_STRIDE) + 2 * xw; d[0] = ireg[g][q].x; d[1] = ireg[g][q].y; }
+            }
+        }
+        if (j_ok) { tile_commit<T>(sJ, jreg, tid); tile_level = top; }
+    };
+    stage_I_group(ml, true);
+    LSTAMP(1);
 
     for (int level = ml; level >= 0; level--) {
         LSTAMP(0);
         const int lw = L.w[level], lh = L.h[level], ls = L.stride[level];
-        const uint8_t* Iorg = level_origin(prevS, L, level);
         const uint8_t* Jorg = level_origin(nextS, L, level);
-        const float lscale = (float)(1. / (1 << level));
-        float prevx = px0 * lscale, prevy = py0 * lscale;
+        __syncthreads();
+        if (level != ml && ((ml - level) & (NPRE - 1)) == 0) {   // pyramids deeper than NPRE levels: the next group of template tiles
+            stage_I_group(level, false);
+            __syncthreads();
+            LSTAMP(1);
+        }
+        const uint8_t* sI = sIall + (level & (NPRE - 1)) * SI_BYTES;
+        float prevx, prevy;
+        int ipx, ipy;
+        const bool inside = template_origin(level, prevx, prevy, ipx, ipy);
         float nx, ny;
-        if (level == ml) { nx = prevx; ny = prevy; }
+        if (level == ml) { const float lscale = __int_as_float((127 - level) << 23); nx = px0 * lscale; ny = py0 * lscale; }
         else { nx = outx * 2.f; ny = outy * 2.f; }
         outx = nx; outy = ny;
-        prevx -= half; prevy -= half;
-        const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
-        if (ipx < -W || ipx >= lw || ipy < -W || ipy >= lh) {   // block-uniform
+        if (!inside) {   // block-uniform
             if (level == 0) { status = 0; err = 0.f; }
             continue;
         }
         int iw00, iw01, iw10, iw11;
         bilinear_weights(prevx - ipx, prevy - ipy, iw00, iw01, iw10, iw11);
-
-        __syncthreads();
-        // ---- stage the 35x35 I tile (rows ipy-1 .. ipy+33, cols ipx-1 .. ipx+33, always inside the padded buffer) as dword copies of
-        // 40-byte rows that start at the 4-byte-aligned column below ipx-1 (35 + 3 <= 40 columns stay inside the 64-pixel frame)
-        const int ax0 = (ipx - 1) & ~3, aoff = (ipx - 1) - ax0;
-        for (int idx = tid; idx < 35 * 10; idx += T) {
-            const int y = idx / 10, xw = idx - y * 10;
-            ((uint32_t*)(sI + y * SI_STRIDE))[xw] = *(const uint32_t*)(Iorg + (ptrdiff_t)(ipy - 1 + y) * ls + ax0 + 4 * xw);
-        }
-        __syncthreads();
+        const int aoff = (ipx - 1) - ((ipx - 1) & ~3);
         // (tile origin (ipx-1, ipy-1) = byte aoff of row 0)
         LSTAMP(1);
         // ---- Scharr (calcSharrDeriv) at the 33x33 sample positions; constant 0 outside the image. Task = (row y, run of SEG columns):
@@ -466,9 +561,22 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
         LSTAMP(3);
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
-        int tx0 = 0, ty0 = 0;
-        bool have_tile = false;
         n_lev++;
+        // Speculative fetch of the NEXT level's search tile around twice this level's start: the loads fly while this level iterates
+        // and are written to LDS after the loop. The iterations of a level move the window by a pixel or two, the 64-pixel tile has
+        // 15 pixels of slack on every side; when the guess misses, the loop below re-stages as before - the result never depends on it.
+        U4A jreg[256 / T];
+        bool pre = false;
+        int ptx0 = 0, pty0 = 0;
+        if (level > 0) {
+            const float gx = (nx + half) * 2.f - half, gy = (ny + half) * 2.f - half;
+            const int pinx = (int)floorf(gx), piny = (int)floorf(gy);
+            if (!(pinx < -W || pinx >= L.w[level - 1] || piny < -W || piny >= L.h[level - 1])) {
+                ptx0 = (pinx - 16) & ~3; pty0 = piny - 16;
+                tile_issue<T>(jreg, level_origin(nextS, L, level - 1), L.stride[level - 1], ptx0, pty0, tid);
+                pre = true;
+            }
+        }
 
         for (int j = 0; j < P.max_iter; j++) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
@@ -477,13 +585,14 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 break;
             }
             int wx = inx - tx0, wy = iny - ty0;
-            if (!have_tile || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
+            if (tile_level != level || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
                 tx0 = (inx - 16) & ~3; ty0 = iny - 16;
                 __syncthreads();
                 stage_J<T>(sJ, Jorg, ls, tx0, ty0, tid);
                 __syncthreads();
-                have_tile = true;
+                tile_level = level;
                 wx = inx - tx0; wy = iny - ty0;
+                if (STAMPS && P.stamps && stamp_on && tid == 0) atomicAdd(&P.stamps[14], 1ull);   // diagnostic: tiles waited for in place
             }
             LSTAMP(9);
             bilinear_weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
@@ -514,7 +623,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             nx += dx; ny += dy;
             outx = nx + half; outy = ny + half;
             n_iter++;
-            if (P.stamps && stamp_on && tid == 0) atomicAdd(&P.stamps[8], 1ull);
+            if (STAMPS && P.stamps && stamp_on && tid == 0) atomicAdd(&P.stamps[8], 1ull);
             if ((double)dx * dx + (double)dy * dy <= P.eps2d) break;
             if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
@@ -522,6 +631,11 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
             }
             pdx = dx; pdy = dy;
             LSTAMP(12);
+        }
+        if (pre) {   // block-uniform
+            __syncthreads();
+            tile_commit<T>(sJ, jreg, tid);
+            tx0 = ptx0; ty0 = pty0; tile_level = level - 1;
         }
         LSTAMP(4);
 
@@ -532,11 +646,12 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
                 status = 0;
             } else {
                 int wx = inx - tx0, wy = iny - ty0;
-                if (!have_tile || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
+                if (tile_level != 0 || wx < 0 || wx > 31 || wy < 0 || wy > 31) {
                     tx0 = (inx - 16) & ~3; ty0 = iny - 16;
                     __syncthreads();
                     stage_J<T>(sJ, Jorg, ls, tx0, ty0, tid);
                     __syncthreads();
+                    tile_level = 0;
                     wx = inx - tx0; wy = iny - ty0;
                 }
                 bilinear_weights(fx - inx, fy - iny, iw00, iw01, iw10, iw11);
@@ -560,6 +675,7 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
         }
     }
     LSTAMP(5);
+    if (STAMPS && P.stamps && stamp_on && tid == 0) atomicAdd(&P.stamps[15], wall_clock64() - wall0);
 #undef LSTAMP
     LKResult res;
     res.x = outx; res.y = outy; res.err = err; res.status = status; res.n_iter = n_iter; res.n_lev = n_lev;
@@ -576,13 +692,14 @@ __device__ __forceinline__ void lk_store(const LKResult& r, int t, const LKParam
     }
 }
 
+template <bool STAMPS>   // STAMPS: the diagnostic build with phase timers (PMV_LK_STAMPS=1); the product launch carries none of that code
 __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS,
                                              PyrLayout L, const float* __restrict__ prev_xy, const int* __restrict__ order, int n, LKParams P,
                                              float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
                                              float* __restrict__ out_err) {
     const int t = order[blockIdx.x];   // block -> track (XCD-aware order built by the host; -1 = no track)
     if (t < 0 || t >= n) return;
-    const LKResult r = lk_track_block<LK_T>(prevS, nextS, L, prev_xy[2 * t], prev_xy[2 * t + 1], P, t == 0);
+    const LKResult r = lk_track_block<LK_T, STAMPS>(prevS, nextS, L, prev_xy[2 * t], prev_xy[2 * t + 1], P, t == 0);
     lk_store(r, t, P, out_xy, out_status, out_err);
 }
 
@@ -590,7 +707,8 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
 // launch. seqs[q] = byte offsets of the prev / next frame slots of sequence q inside `slots`; blocks[b] = (q, track) with track
 // indexing the concatenated coordinate / result arrays (-1 = padding block). All sequences share the frame geometry L.
 constexpr int LKB_T = 64;   // one wavefront per track: throughput form (see block_sum_exact)
-__global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
+template <bool STAMPS>
+__global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
                                                    int n_blocks, PyrLayout L, const float* __restrict__ prev_xy, LKParams P, float* __restrict__ out_xy,
                                                    uint8_t* __restrict__ out_status, float* __restrict__ out_err, uint8_t* __restrict__ out_iters) {
     // grid-stride over the track list: the launcher may cap the grid (PMV_LK_BATCH_BLOCKS) so that the tracks of a round do not occupy
@@ -599,8 +717,8 @@ __global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const int2 bt = blocks[b];
         if (bt.y < 0) continue;
         const LKSeq sq = seqs[bt.x];
-        const LKResult r = lk_track_block<LKB_T>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, P.stamps && (b & 63) == 17);
-        if (P.stamps && (b & 63) == 17 && threadIdx.x == 0) atomicAdd(&P.stamps[13], 1ull);   // diagnostic: sampled tracks
+        const LKResult r = lk_track_block<LKB_T, STAMPS>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, (b & 63) == 17);
+        if (STAMPS && P.stamps && (b & 63) == 17 && threadIdx.x == 0) atomicAdd(&P.stamps[13], 1ull);   // diagnostic: sampled tracks
         lk_store(r, bt.y, P, out_xy, out_status, out_err);
         if (out_iters && threadIdx.x == 0) out_iters[bt.y] = (uint8_t)(r.n_iter > 255 ? 255 : r.n_iter);   // what this track cost: the next launch's ordering hint
         __syncthreads();
@@ -614,7 +732,8 @@ hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* nex
     // every pointer the kernel dereferences: a null base must come back as an error code, never reach a launch
     if (!prev_slot || !next_slot || !d_prev_xy || !d_order || !d_out_xy || !d_status || !d_err || n_blocks < n || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     ProfScope ps(K_LK, s);
-    hipLaunchKernelGGL(k_lk, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
+    if (P.stamps) hipLaunchKernelGGL(k_lk<true>, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
+    else hipLaunchKernelGGL(k_lk<false>, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
     return hipGetLastError();
 }
 
@@ -623,15 +742,18 @@ hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_s
     if (n_blocks <= 0) return hipSuccess;
     if (!slots || !d_seqs || !d_blocks || !d_prev_xy || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     static const int cap = getenv("PMV_LK_BATCH_BLOCKS") ? atoi(getenv("PMV_LK_BATCH_BLOCKS")) : 0;
-    // Occupancy cap of the bulk kernel: 10 KB of LDS per one-wavefront workgroup lets 16 of them fill a CU (160 KB, all four wave slots
-    // of every SIMD at 119 registers), and then every short kernel of the other classes - the 23 launches of an LM solve, the PnP stages,
-    // the detector - waits for LK wavefronts to drain before its workgroups fit anywhere. 12 000 B of unused dynamic LDS on top make it 7
-    // per CU: the LK rounds do not get longer (1555 -> 1601 us at 86 requests with 10 000 B: LK never needed the slots, its wavefronts
+    // Occupancy cap of the bulk kernel: 13.9 KB of LDS per one-wavefront workgroup lets 11 of them share a CU (160 KB; the prefetch
+    // registers of a track, 163 per lane, allow 12), and then every short kernel of the other classes - the 23 launches of an LM solve,
+    // the PnP stages, the detector - waits for LK wavefronts to drain before its workgroups fit anywhere. Unused dynamic LDS on top makes it
+    // 7 per CU (figures below: measured with the 10 KB form of the kernel, where 12 000 B gave the same 7 per CU as 8 300 B does now): the LK rounds do not get longer (1555 -> 1601 us at 86 requests with 10 000 B: LK never needed the slots, its wavefronts
     // mostly wait), the BA rounds drop from 2567 to 1396 us. B = 192, A/B on one box (profiles/r03_batch_exp_k/l/m.log): no cap 49.4 k,
     // 6 000 B 52.9 k, 10 000 B 52.7 / 54.7 k, 12 500 B 55.7 k, 14 000 B 50.7 k frames/s (22 000 B: 43 k at B = 128). PMV_LK_LDS_PAD overrides (0 = no cap).
-    static const int lds_pad = getenv("PMV_LK_LDS_PAD") ? atoi(getenv("PMV_LK_LDS_PAD")) : 12000;
+    static const int lds_pad = getenv("PMV_LK_LDS_PAD") ? atoi(getenv("PMV_LK_LDS_PAD")) : 8300;
     ProfScope ps(K_LK, s);
-    hipLaunchKernelGGL(k_lk_batch, dim3(cap > 0 && cap < n_blocks ? cap : n_blocks), dim3(LKB_T), (size_t)(lds_pad > 0 ? lds_pad : 0), s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err, d_iters);
+    const dim3 grid(cap > 0 && cap < n_blocks ? cap : n_blocks);
+    const size_t pad = (size_t)(lds_pad > 0 ? lds_pad : 0);
+    if (P.stamps) hipLaunchKernelGGL(k_lk_batch<true>, grid, dim3(LKB_T), pad, s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err, d_iters);
+    else hipLaunchKernelGGL(k_lk_batch<false>, grid, dim3(LKB_T), pad, s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err, d_iters);
     return hipGetLastError();
 }
 

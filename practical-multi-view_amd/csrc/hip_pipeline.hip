@@ -10,6 +10,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <malloc.h>
 
 namespace {
 using namespace vo;
@@ -239,6 +240,21 @@ struct BatchBA : BundleAdjustmentBase {
 
 struct pmv_pipeline_result { vo::PipelineRun run; };
 
+// The host threads of a run allocate and free per-frame tables all the time, each in its own glibc arena; with the default tunables an
+// arena gives its top back as soon as 128 KB are free and grows again a frame later - mprotect / madvise calls that take the process's
+// address-space lock. Sampled on a B = 192 run (scripts/hostprof): 30 % of the host CPU time of the timed region in mprotect,
+// __default_morecore, madvise and malloc itself. Keep freed memory in the arenas instead (once per process; PMV_KEEP_MALLOC_DEFAULTS=1
+// leaves the process's settings alone).
+static void host_allocator_setup() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("PMV_KEEP_MALLOC_DEFAULTS")) return;
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_TOP_PAD, 16 << 20);
+        mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    });
+}
+
 extern "C" {
 
 // Same run from HOST frames (n_frames * w * h gray bytes, pageable or pinned): the frames are streamed into slots 0..n_frames-1 by
@@ -261,6 +277,7 @@ int pmv_pipeline_run_streamed(pmv_ctx* ctx, const pmv_pipeline_params* P, const 
 int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K9, const double* gt_poses12,
                      pmv_pipeline_result** out) {
     if (!ctx || !P || !K9 || !gt_poses12 || !out) { pmv::set_err(ctx, "pmv_pipeline_run: null argument"); return PMV_ERR_INVALID; }
+    host_allocator_setup();
     if (P->n_frames < P->init_frames + 2 || P->n_frames > ctx->n_slots || P->init_frames < 1) {
         pmv::set_err(ctx, "pmv_pipeline_run: n_frames=%d (slots %d, init_frames %d)", P->n_frames, ctx->n_slots, P->init_frames);
         return PMV_ERR_CAPACITY;
@@ -316,6 +333,7 @@ int pmv_pipeline_run(pmv_ctx* ctx, const pmv_pipeline_params* P, const double* K
 int pmv_pipeline_run_batch(pmv_ctx* ctx, int B, const pmv_pipeline_params* params, const double* K9, const double* const* gt_poses12,
                            const int* first_slot, pmv_pipeline_result** out) {
     if (!ctx || !params || !K9 || !gt_poses12 || !first_slot || !out || B < 1) { pmv::set_err(ctx, "pmv_pipeline_run_batch: bad argument"); return PMV_ERR_INVALID; }
+    host_allocator_setup();
     for (int b = 0; b < B; b++) {
         const pmv_pipeline_params& P = params[b];
         out[b] = nullptr;

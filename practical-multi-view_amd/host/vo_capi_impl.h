@@ -80,19 +80,10 @@ inline void pipeline_get_poses(const PipelineRun& run, double* out) {
     }
 }
 inline int pipeline_num_frames(const PipelineRun& run) { return (int)run.pipe.frames.size(); }
-inline int pipeline_frame_feature_count(const PipelineRun& run, int k) { return run.pipe.frames[k]->n_features(); }
-inline int pipeline_frame_corr_count(const PipelineRun& run, int k) { return (int)run.pipe.frames[k]->feat_corr.size(); }   // incl. quirk Q10's empty entries
+inline int pipeline_frame_feature_count(const PipelineRun& run, int k) { return run.pipe.frame_feature_count(k); }
+inline int pipeline_frame_corr_count(const PipelineRun& run, int k) { return run.pipe.frame_corr_count(k); }   // incl. quirk Q10's empty entries
 // (column, row, landmark id or -1) per map entry, in the container's iteration order
-inline void pipeline_get_frame_features(const PipelineRun& run, int k, int* out) {
-    const Frame& fr = *run.pipe.frames[k];
-    const LandmarkTable& L = run.pipe.landmarks;
-    int i = 0;
-    fr.for_each_feature([&](int e) {
-        out[3 * i] = fr.column[(size_t)e]; out[3 * i + 1] = fr.row[(size_t)e];
-        out[3 * i + 2] = L.expired(fr.lm[(size_t)e]) ? -1 : fr.lm[(size_t)e];
-        i++;
-    });
-}
+inline void pipeline_get_frame_features(const PipelineRun& run, int k, int* out) { run.pipe.frame_features(k, out); }
 // PIPELINE_STATS_COUNT doubles: counters, run seconds, and per-stage wall seconds of the calling host threads (the field list is
 // documented at pmv_pipeline_get_stats in include/pmv_hip.h)
 constexpr int PIPELINE_STATS_COUNT = 25;

@@ -44,7 +44,8 @@ size_t HashOrder::buckets_for(size_t n) {
 // _M_rehash_aux(n, true_type): the nodes are re-linked in their current order; a node whose new bucket is still empty goes to the
 // FRONT of the list, otherwise behind the first node ("before" node) of its bucket
 void HashOrder::rehash(size_t n) {
-    std::vector<int> nb(n, EMPTY);
+    std::vector<int>& nb = bscratch_;
+    nb.assign(n, EMPTY);
     int p = head_;
     head_ = -1;
     size_t bbegin_bkt = 0;
@@ -517,6 +518,67 @@ void OdometryPipeline::estimatePose(Frame& src, Frame& next) {   // :376-426
     }
 }
 
+// ---- retired frames ------------------------------------------------------------------------------------------------------
+void OdometryPipeline::retire_before(int k_end) {
+    constexpr size_t CHUNK = 1u << 18;   // ints per store chunk
+    for (; retired_upto < k_end; retired_upto++) {
+        const int k = retired_upto;
+        std::shared_ptr<Frame> f;
+        {
+            std::lock_guard<std::mutex> lk(frames_mu);
+            if ((size_t)k >= frames.size() || !frames[(size_t)k] || frames[(size_t)k].use_count() != 1) return;   // still shared (a BA snapshot): next time
+            f = std::move(frames[(size_t)k]);
+            frames[(size_t)k].reset();
+            if (retired.size() < frames.size()) retired.resize(frames.size() + 1024);
+        }
+        RetiredFrame& r = retired[(size_t)k];
+        const size_t need = 3 * (size_t)f->n_features();
+        if (retired_store.empty() || retired_store.back().size() + need > retired_store.back().capacity()) {
+            retired_store.emplace_back();
+            retired_store.back().reserve(std::max(CHUNK, need));
+        }
+        std::vector<int>& st = retired_store.back();
+        r.chunk = retired_store.size() - 1; r.offset = st.size();
+        f->for_each_feature([&](int e) { st.push_back(f->column[(size_t)e]); st.push_back(f->row[(size_t)e]); st.push_back(f->lm[(size_t)e]); });
+        r.n_corr = (int)f->feat_corr.size();
+        r.n_features = f->n_features();
+        std::lock_guard<std::mutex> lk(frames_mu);
+        spare.push_back(std::move(*f));
+    }
+}
+
+Frame OdometryPipeline::take_frame(const ImageView& img) {
+    {
+        std::lock_guard<std::mutex> lk(frames_mu);
+        if (!spare.empty()) {
+            Frame f = std::move(spare.back());
+            spare.pop_back();
+            f.reset(img);
+            return f;
+        }
+    }
+    return Frame(img);
+}
+
+void OdometryPipeline::frame_features(int k, int* out) const {
+    if (frames[(size_t)k]) {
+        const Frame& fr = *frames[(size_t)k];
+        int i = 0;
+        fr.for_each_feature([&](int e) {
+            out[3 * i] = fr.column[(size_t)e]; out[3 * i + 1] = fr.row[(size_t)e];
+            out[3 * i + 2] = landmarks.expired(fr.lm[(size_t)e]) ? -1 : fr.lm[(size_t)e];
+            i++;
+        });
+        return;
+    }
+    const RetiredFrame& r = retired[(size_t)k];
+    const int* src = retired_store[r.chunk].data() + r.offset;
+    for (int i = 0; i < r.n_features; i++) {
+        out[3 * i] = src[3 * i]; out[3 * i + 1] = src[3 * i + 1];
+        out[3 * i + 2] = landmarks.expired(src[3 * i + 2]) ? -1 : src[3 * i + 2];
+    }
+}
+
 void OdometryPipeline::run() {   // startPipeline :247-264 + featureExtractionThread :212-229 + poseEstimationThread :237-243
     for (int i = 0; i < cfg.init_frames; i++) frames.push_back(std::make_shared<Frame>(Frame(images[i])));
     initialise();
@@ -524,13 +586,14 @@ void OdometryPipeline::run() {   // startPipeline :247-264 + featureExtractionTh
     R_s.push_back(Mat3::eye()); t_s.push_back(Vec3{{0, 0, 0}});
     for (int i = init_offset + 1; i < (int)images.size(); i++) {
         if (i >= cfg.stop) break;
-        Frame frame(images[i]);
-        if (frame.isEmpty()) continue;
+        if (images[i].w == 0) continue;   // (Frame::isEmpty)
+        Frame frame = take_frame(images[i]);
         addFrame(frame);
         if (on_frame_added) on_frame_added(frame.frame);
         if (frame.frame < 2) continue;
         const int j = frame.frame - 2;
         estimatePose(*frames[j], *frames[j + 1]);
+        retire_before(j + 1 - std::max(cfg.bundle_size, 2));   // the next job's bundle window starts at j + 3 - bundle_size
     }
 }
 
@@ -567,6 +630,8 @@ void OdometryPipeline::run_threaded() {
                     cv_space.notify_one();
                 }
                 estimatePose(*a, *b);
+                a.reset(); b.reset();
+                retire_before(j + 1 - std::max(cfg.bundle_size, 2));   // the next job's bundle window starts at j + 3 - bundle_size
             }
         } catch (...) {
             back_error = std::current_exception();
@@ -582,8 +647,8 @@ void OdometryPipeline::run_threaded() {
     try {
     for (int i = init_offset + 1; i < (int)images.size(); i++) {
         if (i >= cfg.stop || failed.load()) break;
-        Frame frame(images[i]);
-        if (frame.isEmpty()) continue;
+        if (images[i].w == 0) continue;   // (Frame::isEmpty)
+        Frame frame = take_frame(images[i]);
         {
             // addFrame reads frames[k-1] and appends frames[k]; BA snapshots tracker->frames[i] under the same mutex
             std::unique_lock<std::mutex> lk(mu);

@@ -217,6 +217,21 @@ public:
     // hand-over and BundleAdjustmentBase::apply's window). The Frame objects themselves are never touched by both threads at
     // once. frame_mutex of the reference (OdometryPipeline.h) plays the same role.
     std::mutex frames_mu;
+    // Frames nothing reads any more (older than the bundle window of the job the back-end has finished) are RETIRED: what the exports
+    // need of them - the (column, row, landmark id) triples in the map's iteration order and the size of feat_corr - moves into
+    // `retired`, frames[k] becomes null and the frame's tables (their capacity) go to `spare` for the frames to come. The reference keeps
+    // every Frame alive until the end (~70 KB each: 75 MB per KITTI-00-length sequence); with 192 sequences per process that was 3 GB/s
+    // of fresh heap, and a sixth of the host CPU time of a batched run sat in mprotect / page faults (scripts/hostprof).
+    struct RetiredFrame { int n_features = -1, n_corr = 0; size_t chunk = 0, offset = 0; };
+    std::vector<RetiredFrame> retired;            // per frame number; n_features < 0 = not retired (then frames[k] is alive)
+    std::vector<std::vector<int>> retired_store;  // the triples, in chunks (one allocation per ~1 MB instead of one per frame)
+    std::vector<Frame> spare;                     // guarded by frames_mu
+    int retired_upto = 0;
+    void retire_before(int k_end);                // called by the thread that runs estimatePose, after a job
+    Frame take_frame(const ImageView& img);       // a recycled Frame(img), or a new one
+    int frame_feature_count(int k) const { return frames[(size_t)k] ? frames[(size_t)k]->n_features() : retired[(size_t)k].n_features; }
+    int frame_corr_count(int k) const { return frames[(size_t)k] ? (int)frames[(size_t)k]->feat_corr.size() : retired[(size_t)k].n_corr; }
+    void frame_features(int k, int* out3) const;  // (column, row, landmark id or -1 when the landmark has expired) in iteration order
     std::vector<Mat3> R, R_s;
     std::vector<Vec3> t, t_s;
     BaseFeatureExtractor* extractor = nullptr;

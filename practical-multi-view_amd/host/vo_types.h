@@ -131,6 +131,8 @@ public:
     int next(int node) const { return next_[(size_t)node]; }   // -1 after the last
     size_t bucket_count() const { return nb_; }
     void reserve_nodes(size_t n) { next_.reserve(n); code_.reserve(n); }
+    // an empty table again (one bucket, like a fresh container) that keeps its allocations: the tables of a retired frame serve the next
+    void clear() { next_.clear(); code_.clear(); bprev_.clear(); head_ = -1; nb_ = 1; }
     int insert(size_t code);                                 // a new node (the caller has made sure no equal key exists); returns its index
     template <class Eq> int find(size_t code, Eq eq) const {  // node with this hash code for which eq(node) holds, or -1
         const size_t bkt = code % nb_;
@@ -153,6 +155,7 @@ private:
     std::vector<int> next_;       // per node
     std::vector<size_t> code_;    // per node: cached hash code
     std::vector<int> bprev_;      // per bucket: the node BEFORE the bucket's first node (BEFORE_BEGIN = the list head), EMPTY = no node
+    std::vector<int> bscratch_;   // rehash builds the new bucket array here and swaps: no allocation once both have grown
     int head_ = -1;
     size_t nb_ = 1;
     void rehash(size_t n);
@@ -175,7 +178,7 @@ struct FeatureCorr {
     std::vector<int> key, val;
     HashOrder order;
     size_t size() const { return key.size(); }
-    void clear() { key.clear(); val.clear(); order = HashOrder(); }
+    void clear() { key.clear(); val.clear(); order.clear(); }
 };
 typedef FeatureCorr fmap;
 
@@ -192,6 +195,8 @@ public:
 
     Frame() {}
     explicit Frame(const ImageView& img) : bw(img) {}
+    // a fresh Frame(img) in the storage of an old one (OdometryPipeline recycles the tables of frames nothing reads any more)
+    void reset(const ImageView& img) { column.clear(); row.clear(); lm.clear(); map_order.clear(); feat_corr.clear(); bw = img; frame = 0; }
     bool isEmpty() const { return bw.w == 0; }
     int n_features() const { return (int)lm.size(); }                         // map.size()
     int add_feature(int column_, int row_, int landmark) {                    // map[make_shared<Feature>(..)] = landmark

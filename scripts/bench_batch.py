@@ -55,7 +55,7 @@ for B in Bs:
         ctx.lib.pmv_debug_lk_stamps(ctx.h, out.ctypes.data_as(C.POINTER(C.c_uint64)))
         nt, it = max(1, int(out[13])), max(1, int(out[8]))
         names = ["level-entry", "I-tile", "scharr", "samples+A", "iterations(+J tiles)", "err-pass"]
-        print("        LK stamps:", nt, "sampled tracks; cycles per track:", " ".join("%s=%d" % (nm, int(out[i]) / nt) for i, nm in enumerate(names)), "iterations/track %.1f" % (it / nt))
+        print("        LK stamps:", nt, "sampled tracks; cycles per track:", " ".join("%s=%d" % (nm, int(out[i]) / nt) for i, nm in enumerate(names)), "iterations/track %.1f" % (it / nt), "| tiles waited for in place per track %.2f, wall %.1f us per track (100 MHz counter)" % (int(out[14]) / nt, int(out[15]) / nt / 100.0))
         print("        per iteration: top(tile check / J stage)=%d sample+diff=%d wave-sum=%d update=%d cycles" % tuple(int(out[k]) / it for k in (9, 10, 11, 12)), flush=True)
     for x in r + r2:
         x.free()
