@@ -16,6 +16,9 @@
 #include "backend.h"
 #include "batch_engine.h"
 #include <sys/prctl.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -31,8 +34,10 @@ namespace {
 struct Req {
     int kind = 0;          // 0 LK, 1 GFTT, 2 ShiTomasi | 10 PnP, 11 BA, 12 DLT
     int rc = PMV_OK;
-    bool done = false;
-    std::condition_variable cv;   // only the owner of a finished request is woken (no thundering herd of all waiting sequences)
+    // completion word: the owner sleeps on it (futex), the combiner stores 1 and wakes that one sleeper. No lock is involved: with a
+    // condition variable under the queue's mutex the 50-70 owners of a round woke up one by one into a fight for that mutex, while the
+    // next requests were waiting to get in through the same mutex.
+    std::atomic<int> done{0};
     char err[200] = "";
     virtual ~Req() {}
 };
@@ -234,24 +239,24 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     if (total_tracks > 0) {
         EK(wait_built(E, s, need_round));
         if ((size_t)total_tracks > E->cap_tracks) { fail_all(batch, PMV_ERR_CAPACITY, "more tracks than B * max_tracks", hipSuccess); return; }
-        const size_t off_blocks = (sizeof(LKSeq) * lk.size() + 63) & ~(size_t)63;
-        const size_t off_xy = (off_blocks + sizeof(int2) * (size_t)total_blocks + 63) & ~(size_t)63;
-        const size_t bytes = off_xy + (size_t)total_tracks * 8;
-        EK(C.h_front.ensure(bytes));
-        char* hb = (char*)C.h_front.p;
-        LKSeq* hseq = (LKSeq*)hb;
-        int2* hblk = (int2*)(hb + off_blocks);
-        float* hxy = (float*)(hb + off_xy);
-        int q = 0, bpos = 0;
+        const size_t bytes = sizeof(LKBlock) * (size_t)total_blocks;
+        EK(C.h_front.ensure(bytes + 64));
+        LKBlock* hblk = (LKBlock*)C.h_front.p;
+        int bpos = 0;
         std::vector<LKReq*> live;
+        auto put = [&](const LKReq* r, int o) {
+            if (o < 0) return;   // (padding entries of the striped order: the launch carries real tracks only)
+            LKBlock& k = hblk[bpos++];
+            k.prev_off = (unsigned long long)r->prev_slot * L.slot_bytes;
+            k.next_off = (unsigned long long)r->next_slot * L.slot_bytes;
+            k.track = r->base + o;
+            k.x = r->prev_xy[2 * (size_t)o]; k.y = r->prev_xy[2 * (size_t)o + 1];
+            k.pad = 0;
+        };
         for (LKReq* r : lk) {
             if (r->rc != PMV_OK) continue;
-            hseq[q].prev_off = (unsigned long long)r->prev_slot * L.slot_bytes;
-            hseq[q].next_off = (unsigned long long)r->next_slot * L.slot_bytes;
-            if (!E->lk_lpt) for (int o : r->order) { hblk[bpos].x = q; hblk[bpos].y = o < 0 ? -1 : r->base + o; bpos++; }
-            memcpy(hxy + (size_t)2 * r->base, r->prev_xy, (size_t)r->n * 8);
+            if (!E->lk_lpt) for (int o : r->order) put(r, o);
             live.push_back(r);
-            q++;
         }
         if (E->lk_lpt) {
             // longest-predicted tracks first, over the WHOLE round: every request's order is "most expensive first" (engine_lk), the
@@ -261,12 +266,8 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
             size_t kmax = 0;
             for (LKReq* r : live) kmax = std::max(kmax, r->order.size());
             for (size_t k = 0; k < kmax; k++)
-                for (size_t qi = 0; qi < live.size(); qi++) {
-                    LKReq* r = live[qi];
-                    if (k >= r->order.size()) continue;
-                    const int o = r->order[k];
-                    hblk[bpos].x = (int)qi; hblk[bpos].y = o < 0 ? -1 : r->base + o; bpos++;
-                }
+                for (LKReq* r : live)
+                    if (k < r->order.size()) put(r, r->order[k]);
         }
         LKParams P;
         P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f; P.counters = ctx->d_lk_counters;
@@ -277,9 +278,8 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
             if (!ctx->d_lk_stamps && hipMalloc(&ctx->d_lk_stamps, 16 * 8) == hipSuccess) (void)hipMemset(ctx->d_lk_stamps, 0, 16 * 8);
         }
         P.stamps = lk_stamps ? ctx->d_lk_stamps : nullptr;
-        char* db = C.h_front.dev;   // mapped pinned: every block reads its (sequence, track) record and coordinates once, no copy launch
-        EK(launch_lk_batch(s, ctx->d_slots, (const LKSeq*)db, (const int2*)(db + off_blocks), total_blocks, L, (const float*)(db + off_xy), P,
-                           C.dm_out_xy, C.dm_status, C.dm_err, C.dm_iters));
+        // mapped pinned: every workgroup reads its 32-byte record once, no copy launch
+        EK(launch_lk_batch(s, ctx->d_slots, (const LKBlock*)C.h_front.dev, bpos, L, P, C.dm_out_xy, C.dm_status, C.dm_err, C.dm_iters));
     }
     SYNC_TIMED(C);
     for (LKReq* r : lk) {
@@ -495,6 +495,11 @@ void process_fp(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
     SYNC_TIMED(C);
 }
 
+static inline void futex_wait_while(std::atomic<int>* w, int v) {
+    while (w->load(std::memory_order_acquire) == v) (void)syscall(SYS_futex, (int*)w, FUTEX_WAIT_PRIVATE, v, nullptr, nullptr, 0);
+}
+static inline void futex_wake_one(std::atomic<int>* w) { (void)syscall(SYS_futex, (int*)w, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
+
 void combiner_loop(BatchEngine* E, int role, int lane) {
     Combiner* C = &E->comb[role][lane];
     Queue* Q = &E->queue[role];
@@ -529,10 +534,11 @@ void combiner_loop(BatchEngine* E, int role, int lane) {
         default: process_fp(E, *C, batch); break;
         }
         if (E->exclusive) excl.unlock();
-        {
-            std::lock_guard<std::mutex> lk(Q->mu);
-            C->batches++; C->requests += (long)batch.size();
-            for (Req* r : batch) { r->done = true; r->cv.notify_one(); }   // after this the owner may destroy the request
+        C->batches++; C->requests += (long)batch.size();
+        for (Req* r : batch) {
+            std::atomic<int>* w = &r->done;   // (after the store the owner may return and the request, which lives on its stack, is gone)
+            w->store(1, std::memory_order_release);
+            futex_wake_one(w);
         }
         C->t_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
         { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); C->t_cpu = ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -541,11 +547,11 @@ void combiner_loop(BatchEngine* E, int role, int lane) {
 
 int submit(pmv_ctx* ctx, Queue& Q, Req* r) {
     {
-        std::unique_lock<std::mutex> lk(Q.mu);
+        std::lock_guard<std::mutex> lk(Q.mu);
         Q.pending.push_back(r);
         Q.cv_new.notify_one();
-        r->cv.wait(lk, [&] { return r->done; });
     }
+    futex_wait_while(&r->done, 0);
     if (r->rc != PMV_OK) set_err(ctx, "%s", r->err);
     return r->rc;
 }

@@ -708,16 +708,15 @@ __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, 
 // indexing the concatenated coordinate / result arrays (-1 = padding block). All sequences share the frame geometry L.
 constexpr int LKB_T = 64;   // one wavefront per track: throughput form (see block_sum_exact)
 template <bool STAMPS>
-__global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lk_batch(const uint8_t* __restrict__ slots, const LKSeq* __restrict__ seqs, const int2* __restrict__ blocks,
-                                                   int n_blocks, PyrLayout L, const float* __restrict__ prev_xy, LKParams P, float* __restrict__ out_xy,
+__global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lk_batch(const uint8_t* __restrict__ slots, const LKBlock* __restrict__ blocks,
+                                                   int n_blocks, PyrLayout L, LKParams P, float* __restrict__ out_xy,
                                                    uint8_t* __restrict__ out_status, float* __restrict__ out_err, uint8_t* __restrict__ out_iters) {
     // grid-stride over the track list: the launcher may cap the grid (PMV_LK_BATCH_BLOCKS) so that the tracks of a round do not occupy
     // every register-file slot of the chip while the short launches of the back-end chains wait for one
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        const int2 bt = blocks[b];
-        if (bt.y < 0) continue;
-        const LKSeq sq = seqs[bt.x];
-        const LKResult r = lk_track_block<LKB_T, STAMPS>(slots + sq.prev_off, slots + sq.next_off, L, prev_xy[2 * bt.y], prev_xy[2 * bt.y + 1], P, (b & 63) == 17);
+        const LKBlock bk = blocks[b];   // (every record is a real track: the host drops padding entries)
+        const int2 bt = make_int2(0, bk.track);
+        const LKResult r = lk_track_block<LKB_T, STAMPS>(slots + bk.prev_off, slots + bk.next_off, L, bk.x, bk.y, P, (b & 63) == 17);
         if (STAMPS && P.stamps && (b & 63) == 17 && threadIdx.x == 0) atomicAdd(&P.stamps[13], 1ull);   // diagnostic: sampled tracks
         lk_store(r, bt.y, P, out_xy, out_status, out_err);
         if (out_iters && threadIdx.x == 0) out_iters[bt.y] = (uint8_t)(r.n_iter > 255 ? 255 : r.n_iter);   // what this track cost: the next launch's ordering hint
@@ -737,10 +736,10 @@ hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* nex
     return hipGetLastError();
 }
 
-hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_seqs, const int2* d_blocks, int n_blocks, const PyrLayout& L,
-                           const float* d_prev_xy, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err, uint8_t* d_iters) {
+hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKBlock* d_blocks, int n_blocks, const PyrLayout& L,
+                           const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err, uint8_t* d_iters) {
     if (n_blocks <= 0) return hipSuccess;
-    if (!slots || !d_seqs || !d_blocks || !d_prev_xy || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
+    if (!slots || !d_blocks || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     static const int cap = getenv("PMV_LK_BATCH_BLOCKS") ? atoi(getenv("PMV_LK_BATCH_BLOCKS")) : 0;
     // Occupancy cap of the bulk kernel: 13.9 KB of LDS per one-wavefront workgroup lets 11 of them share a CU (160 KB; the prefetch
     // registers of a track, 163 per lane, allow 12), and then every short kernel of the other classes - the 23 launches of an LM solve,
@@ -752,8 +751,8 @@ hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_s
     ProfScope ps(K_LK, s);
     const dim3 grid(cap > 0 && cap < n_blocks ? cap : n_blocks);
     const size_t pad = (size_t)(lds_pad > 0 ? lds_pad : 0);
-    if (P.stamps) hipLaunchKernelGGL(k_lk_batch<true>, grid, dim3(LKB_T), pad, s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err, d_iters);
-    else hipLaunchKernelGGL(k_lk_batch<false>, grid, dim3(LKB_T), pad, s, slots, d_seqs, d_blocks, n_blocks, L, d_prev_xy, P, d_out_xy, d_status, d_err, d_iters);
+    if (P.stamps) hipLaunchKernelGGL(k_lk_batch<true>, grid, dim3(LKB_T), pad, s, slots, d_blocks, n_blocks, L, P, d_out_xy, d_status, d_err, d_iters);
+    else hipLaunchKernelGGL(k_lk_batch<false>, grid, dim3(LKB_T), pad, s, slots, d_blocks, n_blocks, L, P, d_out_xy, d_status, d_err, d_iters);
     return hipGetLastError();
 }
 

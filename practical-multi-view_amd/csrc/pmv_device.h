@@ -130,9 +130,16 @@ struct LKParams {
     unsigned long long* counters; // [0] += LK iterations executed (all levels), [1] += (track, level) pairs that iterated, [2] += tracks
 };
 
-struct LKSeq { unsigned long long prev_off, next_off; };   // byte offsets of a sequence's prev / next frame slot (k_lk_batch)
-hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKSeq* d_seqs, const int2* d_blocks, int n_blocks, const PyrLayout& L,
-                           const float* d_prev_xy, const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err, uint8_t* d_iters = nullptr /* optional: LK iterations per track */);
+// one workgroup of k_lk_batch: everything it needs to start in ONE 32-byte record (the records sit in mapped pinned host memory: a wave's
+// first load is a round trip over PCIe, and it used to make three dependent ones - block -> sequence -> coordinates)
+struct __attribute__((aligned(32))) LKBlock {
+    unsigned long long prev_off, next_off;   // byte offsets of the sequence's prev / next frame slot
+    float x, y;                              // the track's position in the prev frame
+    int track;                               // index into the concatenated result arrays
+    int pad;
+};
+hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKBlock* d_blocks, int n_blocks, const PyrLayout& L, const LKParams& P,
+                           float* d_out_xy, uint8_t* d_status, float* d_err, uint8_t* d_iters = nullptr);
 hipError_t launch_bgr2gray(hipStream_t s, const uint8_t* d_bgr, int w, int h, int stride, uint8_t* d_gray);   // cv::cvtColor(BGR2GRAY), 8-bit
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n, const uint8_t* tight = nullptr /* tight gray frames to take level 0 from; null: in place */);
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int level_dst, int first_slot, int n);
