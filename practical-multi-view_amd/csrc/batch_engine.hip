@@ -80,6 +80,8 @@ struct Queue {   // pending requests of one kernel class
     std::mutex mu;
     std::condition_variable cv_new;
     std::vector<Req*> pending;
+    std::chrono::steady_clock::time_point first_arrival;   // when `pending` last went from empty to non-empty
+    int min_batch = 0;     // copy of BatchEngine::min_batch of the class: submit() wakes a combiner at the first and at the min_batch-th request only
     bool stop = false;
 };
 constexpr int MAX_LANES = 4;
@@ -95,12 +97,13 @@ struct Combiner {
     double t_cpu = 0;                            // CPU seconds of the combiner thread itself
     // LK staging + mapped pinned result blocks; detector buffers (only used by combiners of those classes)
     Growable h_front{nullptr, 0, true}, d_front, h_cells{nullptr, 0, true}, d_cells, d_eig, d_cellmax, d_spill, d_det_xy, d_det_score, d_det_count, h_det{nullptr, 0, true};
-    float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr; uint8_t* h_iters = nullptr;
-    float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr; uint8_t* dm_iters = nullptr;
+    float* h_out_xy = nullptr; float* h_err = nullptr; uint8_t* h_status = nullptr; uint16_t* h_work = nullptr;
+    float* dm_out_xy = nullptr; float* dm_err = nullptr; uint8_t* dm_status = nullptr; uint16_t* dm_work = nullptr;
     int* d_flags = nullptr;
     // completion word of the "flag" wait: the last launch of a round is k_signal, which stores the round number into mapped pinned memory
     unsigned* h_done = nullptr; unsigned* dm_done = nullptr; unsigned done_seq = 0;
     double ema_wait_us = 0;            // smoothed duration of the wait of a round (how long to sleep before the first look)
+    long n_polls = 0; double t_first_sleep = 0, t_prep = 0, t_post = 0;   // diagnostic (PMV_BATCH_TIMING=1, printed when the engine goes)
 };
 
 __global__ void k_signal(unsigned* done, unsigned seq) { BACKEND_PRIO(); __threadfence_system(); __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -121,6 +124,12 @@ struct BatchEngine {
     pmv_ctx* ctx = nullptr;
     int B = 0;
     int linger_us = 0;
+    // Round-forming policy: a combiner that finds fewer than min_batch[class] requests waiting gives the others up to max_linger_us
+    // (counted from the arrival of the oldest one) to join. Without it the classes have a second, stable operating point - lanes firing as
+    // soon as anything is pending, rounds of a third of the size, the fixed cost of a round (launches, completion signal, wake-ups) paid
+    // three times as often: the same binary then ran at 53 k instead of 65-69 k frames/s in one run out of five (profiles/r03_batch_exp_af.log).
+    int min_batch[R_COUNT] = {0, 0, 0, 0, 0, 0};
+    int max_linger_us = 300;
     int wait_mode = 3;   // 0 spin (hipStreamSynchronize), 1 query + yield, 2 blocking event, 3 completion word + timed sleeps
     std::vector<BackendBuffers*> slots;   // one back-end workspace set per concurrent sequence
     // combiners (thread + stream) per class. Round 2, host-bound: 2 and 3 per class cost more host CPU (smaller batches) than they won in
@@ -185,9 +194,10 @@ hipError_t wait_stream(BatchEngine* E, Combiner& C) {
     auto done = [&] { return __atomic_load_n(C.h_done, __ATOMIC_ACQUIRE) == seq; };
     if (!done()) {
         const double first = 0.7 * C.ema_wait_us;
-        if (first > 25) std::this_thread::sleep_for(std::chrono::nanoseconds((long)(first * 1e3)));
+        if (first > 25) { std::this_thread::sleep_for(std::chrono::nanoseconds((long)(first * 1e3))); C.t_first_sleep += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
         int looks = 0;
         while (!done()) {
+            C.n_polls++;
             std::this_thread::sleep_for(std::chrono::microseconds(10));
             if ((++looks & 255) == 0) {   // a faulted launch never signals: ask the runtime now and then
                 e = hipStreamQuery(C.s);
@@ -270,7 +280,7 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
                     if (k < r->order.size()) put(r, r->order[k]);
         }
         LKParams P;
-        P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f; P.counters = ctx->d_lk_counters;
+        P.max_iter = 30; P.eps2 = 1e-4f; P.eps2d = 0.01 * 0.01; P.min_eig = 1e-4f;
         static const bool lk_stamps = getenv("PMV_LK_STAMPS") != nullptr;   // diagnostic: phase timers of every 64th track (pmv_debug_lk_stamps)
         if (lk_stamps) {
             static std::mutex stamps_mu;   // two LK lanes
@@ -279,7 +289,7 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
         }
         P.stamps = lk_stamps ? ctx->d_lk_stamps : nullptr;
         // mapped pinned: every workgroup reads its 32-byte record once, no copy launch
-        EK(launch_lk_batch(s, ctx->d_slots, (const LKBlock*)C.h_front.dev, bpos, L, P, C.dm_out_xy, C.dm_status, C.dm_err, C.dm_iters));
+        EK(launch_lk_batch(s, ctx->d_slots, (const LKBlock*)C.h_front.dev, bpos, L, P, C.dm_out_xy, C.dm_status, C.dm_err, C.dm_work));
     }
     SYNC_TIMED(C);
     for (LKReq* r : lk) {
@@ -287,7 +297,8 @@ void process_lk(BatchEngine* E, Combiner& C, std::vector<Req*>& batch) {
         memcpy(r->out_xy, C.h_out_xy + (size_t)2 * r->base, (size_t)r->n * 8);
         memcpy(r->status, C.h_status + r->base, (size_t)r->n);
         memcpy(r->err_out, C.h_err + r->base, (size_t)r->n * 4);
-        if (r->iters_out) memcpy(r->iters_out, C.h_iters + r->base, (size_t)r->n);
+        if (r->iters_out) for (int i = 0; i < r->n; i++) r->iters_out[i] = (uint8_t)(C.h_work[(size_t)r->base + i] & 0xffu);
+        ctx->add_lk_work(C.h_work + r->base, (size_t)r->n);
     }
 }
 
@@ -513,6 +524,11 @@ void combiner_loop(BatchEngine* E, int role, int lane) {
             std::unique_lock<std::mutex> lk(Q->mu);
             Q->cv_new.wait(lk, [&] { return !Q->pending.empty() || Q->stop; });
             if (Q->pending.empty() && Q->stop) return;
+            if (E->min_batch[role] > 1 && (int)Q->pending.size() < E->min_batch[role] && !Q->stop) {
+                const auto deadline = Q->first_arrival + std::chrono::microseconds(E->max_linger_us);
+                Q->cv_new.wait_until(lk, deadline, [&] { return (int)Q->pending.size() >= E->min_batch[role] || Q->stop; });
+                if (Q->pending.empty()) { if (Q->stop) return; continue; }   // another lane of the class took them meanwhile
+            }
             if (E->linger_us > 0 && (int)Q->pending.size() < E->B) {   // optional: give stragglers a moment to join the batch
                 lk.unlock();
                 std::this_thread::sleep_for(std::chrono::microseconds(E->linger_us));
@@ -548,8 +564,11 @@ void combiner_loop(BatchEngine* E, int role, int lane) {
 int submit(pmv_ctx* ctx, Queue& Q, Req* r) {
     {
         std::lock_guard<std::mutex> lk(Q.mu);
+        if (Q.pending.empty()) Q.first_arrival = std::chrono::steady_clock::now();
         Q.pending.push_back(r);
-        Q.cv_new.notify_one();
+        const int sz = (int)Q.pending.size();
+        if (sz == 1) Q.cv_new.notify_one();
+        else if (Q.min_batch <= 1 || sz == Q.min_batch) Q.cv_new.notify_all();   // (a lingering combiner is waiting for exactly this)
     }
     futex_wait_while(&r->done, 0);
     if (r->rc != PMV_OK) set_err(ctx, "%s", r->err);
@@ -571,6 +590,10 @@ void batch_engine_destroy(pmv_ctx* ctx) {
     for (auto& role : E->comb)
         for (Combiner& C : role) {
             if (C.th.joinable()) C.th.join();
+            if (getenv("PMV_BATCH_TIMING") && C.batches)
+                fprintf(stderr, "[batch-timing] class %d lane %d: %ld rounds, %.1f req/round, per round: work %.0f us, sync %.0f us (first sleep %.0f us, then %.1f polls), cpu %.0f us, ema %.0f us\n",
+                        (int)(&role - &E->comb[0]), (int)(&C - &role[0]), C.batches, (double)C.requests / C.batches, C.t_work / C.batches * 1e6, C.t_sync / C.batches * 1e6,
+                        C.t_first_sleep / C.batches * 1e6, (double)C.n_polls / C.batches, C.t_cpu / C.batches * 1e6, C.ema_wait_us);
             if (C.s) { (void)hipStreamSynchronize(C.s); (void)hipStreamDestroy(C.s); }
             if (C.ev) (void)hipEventDestroy(C.ev);
             if (C.h_done) (void)hipHostFree(C.h_done);
@@ -578,7 +601,7 @@ void batch_engine_destroy(pmv_ctx* ctx) {
             if (C.h_out_xy) (void)hipHostFree(C.h_out_xy);
             if (C.h_err) (void)hipHostFree(C.h_err);
             if (C.h_status) (void)hipHostFree(C.h_status);
-            if (C.h_iters) (void)hipHostFree(C.h_iters);
+            if (C.h_work) (void)hipHostFree(C.h_work);
             if (C.d_flags) (void)hipFree(C.d_flags);
         }
     if (E->build_thread.joinable()) E->build_thread.join();
@@ -597,6 +620,11 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
     ctx->engine = E;
     E->ctx = ctx; E->B = B;
     if (const char* e = getenv("PMV_BATCH_LINGER_US")) E->linger_us = atoi(e);
+    {
+        const double frac = getenv("PMV_BATCH_MIN_FRAC") ? atof(getenv("PMV_BATCH_MIN_FRAC")) : 0.12;   // of the B sequences, per class with long rounds
+        if (const char* e = getenv("PMV_BATCH_MAX_LINGER_US")) E->max_linger_us = atoi(e);
+        for (int r : {(int)R_LK, (int)R_PNP, (int)R_BA}) { E->min_batch[r] = (int)(frac * B); E->queue[r].min_batch = E->min_batch[r]; }
+    }
     for (int i = 0; i < B; i++) {
         BackendBuffers* b = nullptr;
         const int rc = backend_alloc(ctx, &b);
@@ -607,6 +635,7 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
     if (const char* e = getenv("PMV_BATCH_EXCLUSIVE")) E->exclusive = atoi(e) != 0;
     if (const char* e = getenv("PMV_LK_LPT")) E->lk_lpt = atoi(e) != 0;
     E->lanes[R_LK] = 2;   // (measured, B = 128: see DESIGN.md §5)
+    E->lanes[R_BA] = 2;   // (B = 192, profiles/r03_batch_exp_ae.log: 64.8 k -> 67.6 k frames/s; three lanes: 52 k)
     if (const char* e = getenv("PMV_BATCH_LANES")) for (int& l : E->lanes) l = std::max(1, std::min(MAX_LANES, atoi(e)));
     if (const char* e = getenv("PMV_BATCH_LANES_LK")) E->lanes[R_LK] = std::max(1, std::min(MAX_LANES, atoi(e)));
     if (const char* e = getenv("PMV_BATCH_LANES_PNP")) E->lanes[R_PNP] = std::max(1, std::min(MAX_LANES, atoi(e)));
@@ -632,8 +661,8 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
                 CKC(hipHostMalloc(&C.h_out_xy, E->cap_tracks * 8, hipHostMallocMapped | hipHostMallocCoherent));
                 CKC(hipHostMalloc(&C.h_status, E->cap_tracks, hipHostMallocMapped | hipHostMallocCoherent));
                 CKC(hipHostMalloc(&C.h_err, E->cap_tracks * 4, hipHostMallocMapped | hipHostMallocCoherent));
-                CKC(hipHostMalloc(&C.h_iters, E->cap_tracks, hipHostMallocMapped | hipHostMallocCoherent));
-                CKC(hipHostGetDevicePointer((void**)&C.dm_iters, C.h_iters, 0));
+                CKC(hipHostMalloc(&C.h_work, E->cap_tracks * 2, hipHostMallocMapped | hipHostMallocCoherent));
+                CKC(hipHostGetDevicePointer((void**)&C.dm_work, C.h_work, 0));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_out_xy, C.h_out_xy, 0));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_status, C.h_status, 0));
                 CKC(hipHostGetDevicePointer((void**)&C.dm_err, C.h_err, 0));

@@ -103,8 +103,9 @@ int pmv_ctx_create(pmv_ctx** out, int device, int max_w, int max_h, int n_slots,
     CK(hipHostGetDevicePointer((void**)&c->dm_err, c->h_err, 0));
     CK(hipMalloc(&c->d_knn, nt * 16 + 64));
     CK(hipHostMalloc(&c->h_knn, nt * 16 + 64));
-    CK(hipMalloc(&c->d_lk_counters, 32));
-    CK(hipMemset(c->d_lk_counters, 0, 32));
+    CK(hipHostMalloc(&c->h_work, (size_t)nt * 2, hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipHostGetDevicePointer((void**)&c->dm_work, c->h_work, 0));
+    for (auto& a : c->lk_work) a.store(0);
     CK(hipMalloc(&c->d_cells, MAX_CELLS * CELL_STRIDE * 4));
     CK(hipHostMalloc(&c->h_cells, MAX_CELLS * CELL_STRIDE * 4));
     CK(hipMalloc(&c->d_eig, (size_t)MAX_CELLS * CELL_PIX * sizeof(double)));   // shared by GFTT (f32) and ShiTomasi (f64)
@@ -142,7 +143,7 @@ void pmv_ctx_destroy(pmv_ctx* c) {
     backend_destroy(c);
     c->prof.destroy();
     if (c->d_lk_stamps) hipFree(c->d_lk_stamps);
-    if (c->d_lk_counters) hipFree(c->d_lk_counters);
+    if (c->h_work) hipHostFree(c->h_work);
     if (c->d_knn) hipFree(c->d_knn);
     if (c->h_knn) hipHostFree(c->h_knn);
     hipFree(c->d_slots); hipFree(c->d_prev_xy); hipFree(c->d_out_xy); hipFree(c->d_status); hipFree(c->d_err);
@@ -334,13 +335,13 @@ int pmv_lk_track(pmv_ctx* ctx, int prev_slot, int next_slot, const float* prev_x
     static const bool lk_stamps = getenv("PMV_LK_STAMPS") != nullptr;   // read once per process
     if (!ctx->d_lk_stamps && lk_stamps) { CKC(hipMalloc(&ctx->d_lk_stamps, 16 * 8)); CKC(hipMemset(ctx->d_lk_stamps, 0, 16 * 8)); }
     P.stamps = ctx->d_lk_stamps;
-    P.counters = ctx->d_lk_counters;
     CKC(launch_lk(ctx->s_front, ctx->d_slots + (size_t)prev_slot * L.slot_bytes, ctx->d_slots + (size_t)next_slot * L.slot_bytes,
-                  L, ctx->d_prev_xy, (const int*)(ctx->d_prev_xy + (size_t)2 * n), nb, n, P, ctx->dm_out_xy, ctx->dm_status, ctx->dm_err));
+                  L, ctx->d_prev_xy, (const int*)(ctx->d_prev_xy + (size_t)2 * n), nb, n, P, ctx->dm_out_xy, ctx->dm_status, ctx->dm_err, ctx->dm_work));
     CKC(hipStreamSynchronize(ctx->s_front));   // the kernel wrote positions / status / err straight into mapped pinned memory
     memcpy(out_xy, ctx->h_out_xy, (size_t)n * 8);
     memcpy(out_status, ctx->h_status, (size_t)n);
     memcpy(out_err, ctx->h_err, (size_t)n * 4);
+    ctx->add_lk_work(ctx->h_work, (size_t)n);
     return PMV_OK;
 }
 
@@ -470,8 +471,7 @@ int pmv_lk_counters(pmv_ctx* ctx, unsigned long long* out3, int reset) {
     REQ(ctx && out3, PMV_ERR_INVALID, "null argument");
     CKC(hipSetDevice(ctx->device));
     CKC(hipStreamSynchronize(ctx->s_front));
-    CKC(hipMemcpy(out3, ctx->d_lk_counters, 24, hipMemcpyDeviceToHost));
-    if (reset) CKC(hipMemset(ctx->d_lk_counters, 0, 32));
+    for (int i = 0; i < 3; i++) out3[i] = reset ? ctx->lk_work[i].exchange(0) : ctx->lk_work[i].load();
     return PMV_OK;
 }
 int pmv_prof_kernel_count(void) { return K_COUNT; }

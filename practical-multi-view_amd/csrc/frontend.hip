@@ -682,13 +682,13 @@ __device__ __forceinline__ LKResult lk_track_block(const uint8_t* __restrict__ p
     return res;
 }
 
-__device__ __forceinline__ void lk_store(const LKResult& r, int t, const LKParams& P, float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
-                                         float* __restrict__ out_err) {
+__device__ __forceinline__ void lk_store(const LKResult& r, int t, float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
+                                         float* __restrict__ out_err, uint16_t* __restrict__ out_work) {
     if (threadIdx.x == 0) {
         out_xy[2 * t] = r.x; out_xy[2 * t + 1] = r.y;
         out_status[t] = (uint8_t)r.status;
         out_err[t] = r.err;
-        if (P.counters) { atomicAdd(&P.counters[0], (unsigned long long)r.n_iter); atomicAdd(&P.counters[1], (unsigned long long)r.n_lev); atomicAdd(&P.counters[2], 1ull); }
+        if (out_work) out_work[t] = (uint16_t)(r.n_iter | (r.n_lev << 8));   // <= 5 x 30 iterations, <= 5 levels
     }
 }
 
@@ -696,11 +696,11 @@ template <bool STAMPS>   // STAMPS: the diagnostic build with phase timers (PMV_
 __global__ __launch_bounds__(LK_T) void k_lk(const uint8_t* __restrict__ prevS, const uint8_t* __restrict__ nextS,
                                              PyrLayout L, const float* __restrict__ prev_xy, const int* __restrict__ order, int n, LKParams P,
                                              float* __restrict__ out_xy, uint8_t* __restrict__ out_status,
-                                             float* __restrict__ out_err) {
+                                             float* __restrict__ out_err, uint16_t* __restrict__ out_work) {
     const int t = order[blockIdx.x];   // block -> track (XCD-aware order built by the host; -1 = no track)
     if (t < 0 || t >= n) return;
     const LKResult r = lk_track_block<LK_T, STAMPS>(prevS, nextS, L, prev_xy[2 * t], prev_xy[2 * t + 1], P, t == 0);
-    lk_store(r, t, P, out_xy, out_status, out_err);
+    lk_store(r, t, out_xy, out_status, out_err, out_work);
 }
 
 // Batched form ("same kernels with a leading batch dimension"): the blocks of several independent sequences in one
@@ -710,7 +710,7 @@ constexpr int LKB_T = 64;   // one wavefront per track: throughput form (see blo
 template <bool STAMPS>
 __global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lk_batch(const uint8_t* __restrict__ slots, const LKBlock* __restrict__ blocks,
                                                    int n_blocks, PyrLayout L, LKParams P, float* __restrict__ out_xy,
-                                                   uint8_t* __restrict__ out_status, float* __restrict__ out_err, uint8_t* __restrict__ out_iters) {
+                                                   uint8_t* __restrict__ out_status, float* __restrict__ out_err, uint16_t* __restrict__ out_work) {
     // grid-stride over the track list: the launcher may cap the grid (PMV_LK_BATCH_BLOCKS) so that the tracks of a round do not occupy
     // every register-file slot of the chip while the short launches of the back-end chains wait for one
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
@@ -718,41 +718,41 @@ __global__ __launch_bounds__(LKB_T) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         const int2 bt = make_int2(0, bk.track);
         const LKResult r = lk_track_block<LKB_T, STAMPS>(slots + bk.prev_off, slots + bk.next_off, L, bk.x, bk.y, P, (b & 63) == 17);
         if (STAMPS && P.stamps && (b & 63) == 17 && threadIdx.x == 0) atomicAdd(&P.stamps[13], 1ull);   // diagnostic: sampled tracks
-        lk_store(r, bt.y, P, out_xy, out_status, out_err);
-        if (out_iters && threadIdx.x == 0) out_iters[bt.y] = (uint8_t)(r.n_iter > 255 ? 255 : r.n_iter);   // what this track cost: the next launch's ordering hint
+        lk_store(r, bt.y, out_xy, out_status, out_err, out_work);   // (out_work: what this track cost - the next launch's ordering hint, and OPS_lk)
         __syncthreads();
     }
 }
 
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
                      const float* d_prev_xy, const int* d_order, int n_blocks, int n, const LKParams& P, float* d_out_xy,
-                     uint8_t* d_status, float* d_err) {
+                     uint8_t* d_status, float* d_err, uint16_t* d_work) {
     if (n <= 0) return hipSuccess;
     // every pointer the kernel dereferences: a null base must come back as an error code, never reach a launch
     if (!prev_slot || !next_slot || !d_prev_xy || !d_order || !d_out_xy || !d_status || !d_err || n_blocks < n || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     ProfScope ps(K_LK, s);
-    if (P.stamps) hipLaunchKernelGGL(k_lk<true>, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
-    else hipLaunchKernelGGL(k_lk<false>, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err);
+    if (P.stamps) hipLaunchKernelGGL(k_lk<true>, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err, d_work);
+    else hipLaunchKernelGGL(k_lk<false>, dim3(n_blocks), dim3(LK_T), 0, s, prev_slot, next_slot, L, d_prev_xy, d_order, n, P, d_out_xy, d_status, d_err, d_work);
     return hipGetLastError();
 }
 
 hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKBlock* d_blocks, int n_blocks, const PyrLayout& L,
-                           const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err, uint8_t* d_iters) {
+                           const LKParams& P, float* d_out_xy, uint8_t* d_status, float* d_err, uint16_t* d_work) {
     if (n_blocks <= 0) return hipSuccess;
     if (!slots || !d_blocks || !d_out_xy || !d_status || !d_err || L.n_levels < 1 || L.n_levels > MAX_LEVELS) return hipErrorInvalidValue;
     static const int cap = getenv("PMV_LK_BATCH_BLOCKS") ? atoi(getenv("PMV_LK_BATCH_BLOCKS")) : 0;
     // Occupancy cap of the bulk kernel: 13.9 KB of LDS per one-wavefront workgroup lets 11 of them share a CU (160 KB; the prefetch
-    // registers of a track, 163 per lane, allow 12), and then every short kernel of the other classes - the 23 launches of an LM solve,
-    // the PnP stages, the detector - waits for LK wavefronts to drain before its workgroups fit anywhere. Unused dynamic LDS on top makes it
-    // 7 per CU (figures below: measured with the 10 KB form of the kernel, where 12 000 B gave the same 7 per CU as 8 300 B does now): the LK rounds do not get longer (1555 -> 1601 us at 86 requests with 10 000 B: LK never needed the slots, its wavefronts
-    // mostly wait), the BA rounds drop from 2567 to 1396 us. B = 192, A/B on one box (profiles/r03_batch_exp_k/l/m.log): no cap 49.4 k,
-    // 6 000 B 52.9 k, 10 000 B 52.7 / 54.7 k, 12 500 B 55.7 k, 14 000 B 50.7 k frames/s (22 000 B: 43 k at B = 128). PMV_LK_LDS_PAD overrides (0 = no cap).
-    static const int lds_pad = getenv("PMV_LK_LDS_PAD") ? atoi(getenv("PMV_LK_LDS_PAD")) : 8300;
+    // registers of a track, ~150 per lane, allow 12), and then every short kernel of the other classes - the 23 launches of an LM solve,
+    // the PnP stages, the detector - waits for LK wavefronts to drain before its workgroups fit anywhere. Unused dynamic LDS on top caps it:
+    // 5 000 B = 8 per CU. B = 192, same box, profiles/r03_batch_exp_ae/af.log (after the per-track atomics were gone, which had made
+    // the cap look far more valuable than it is: with them every extra resident wavefront was one more contender for three L2 lines):
+    // no cap 64.8 k, 2 000 B 63.4 k, 3 000 B 65.6 k, 4 000 B 62.7-68.7 k, 5 000 B 69.0 k, 6 500 B 68.3 k frames/s (run-to-run spread of one
+    // setting: +-3 k). PMV_LK_LDS_PAD overrides (0 = no cap).
+    static const int lds_pad = getenv("PMV_LK_LDS_PAD") ? atoi(getenv("PMV_LK_LDS_PAD")) : 5000;
     ProfScope ps(K_LK, s);
     const dim3 grid(cap > 0 && cap < n_blocks ? cap : n_blocks);
     const size_t pad = (size_t)(lds_pad > 0 ? lds_pad : 0);
-    if (P.stamps) hipLaunchKernelGGL(k_lk_batch<true>, grid, dim3(LKB_T), pad, s, slots, d_blocks, n_blocks, L, P, d_out_xy, d_status, d_err, d_iters);
-    else hipLaunchKernelGGL(k_lk_batch<false>, grid, dim3(LKB_T), pad, s, slots, d_blocks, n_blocks, L, P, d_out_xy, d_status, d_err, d_iters);
+    if (P.stamps) hipLaunchKernelGGL(k_lk_batch<true>, grid, dim3(LKB_T), pad, s, slots, d_blocks, n_blocks, L, P, d_out_xy, d_status, d_err, d_work);
+    else hipLaunchKernelGGL(k_lk_batch<false>, grid, dim3(LKB_T), pad, s, slots, d_blocks, n_blocks, L, P, d_out_xy, d_status, d_err, d_work);
     return hipGetLastError();
 }
 

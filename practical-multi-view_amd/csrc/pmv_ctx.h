@@ -1,5 +1,6 @@
 // Internal context definition shared by the C-ABI translation units.
 #pragma once
+#include <atomic>
 #include "pmv_device.h"
 #include "pmv_prof.h"
 #include "../../include/pmv_hip.h"
@@ -44,7 +45,9 @@ struct pmv_ctx {
     uint8_t* dm_status = nullptr;
     int *h_knn = nullptr, *d_knn = nullptr;      // kNN matcher coordinates: [src 2n | cmp 2m] ints, 2 * max_tracks pairs
     unsigned long long* d_lk_stamps = nullptr;   // diagnostic (PMV_LK_STAMPS=1)
-    unsigned long long* d_lk_counters = nullptr; // 4 x u64 work counters (iterations, level passes, tracks), see pmv_lk_counters
+    uint16_t* h_work = nullptr; uint16_t* dm_work = nullptr;   // per-track LK work of pmv_lk_track (mapped pinned, see launch_lk)
+    std::atomic<unsigned long long> lk_work[3];  // host-side sums: LK iterations, level passes, tracks (pmv_lk_counters)
+    void add_lk_work(const uint16_t* w, size_t n) { unsigned long long it = 0, lv = 0; for (size_t i = 0; i < n; i++) { it += w[i] & 0xffu; lv += w[i] >> 8; } lk_work[0] += it; lk_work[1] += lv; lk_work[2] += n; }
     // detectors
     int* d_cells = nullptr;
     int* h_cells = nullptr;   // pinned staging of the device cell records

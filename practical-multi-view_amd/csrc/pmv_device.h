@@ -127,7 +127,6 @@ struct LKParams {
     double eps2d;     // epsilon^2 = 1e-4
     float min_eig;    // 1e-4
     unsigned long long* stamps;   // optional (diagnostic): 16 shader-clock phase timers accumulated by the block of track 0
-    unsigned long long* counters; // [0] += LK iterations executed (all levels), [1] += (track, level) pairs that iterated, [2] += tracks
 };
 
 // one workgroup of k_lk_batch: everything it needs to start in ONE 32-byte record (the records sit in mapped pinned host memory: a wave's
@@ -139,13 +138,16 @@ struct __attribute__((aligned(32))) LKBlock {
     int pad;
 };
 hipError_t launch_lk_batch(hipStream_t s, const uint8_t* slots, const LKBlock* d_blocks, int n_blocks, const PyrLayout& L, const LKParams& P,
-                           float* d_out_xy, uint8_t* d_status, float* d_err, uint8_t* d_iters = nullptr);
+                           float* d_out_xy, uint8_t* d_status, float* d_err, uint16_t* d_work = nullptr);
 hipError_t launch_bgr2gray(hipStream_t s, const uint8_t* d_bgr, int w, int h, int stride, uint8_t* d_gray);   // cv::cvtColor(BGR2GRAY), 8-bit
 hipError_t launch_pad_level0(hipStream_t s, uint8_t* slots, const PyrLayout& L, int first_slot, int n, const uint8_t* tight = nullptr /* tight gray frames to take level 0 from; null: in place */);
 hipError_t launch_pyrdown(hipStream_t s, uint8_t* slots, const PyrLayout& L, int level_dst, int first_slot, int n);
 hipError_t launch_lk(hipStream_t s, const uint8_t* prev_slot, const uint8_t* next_slot, const PyrLayout& L,
                      const float* d_prev_xy, const int* d_order, int n_blocks, int n, const LKParams& P, float* d_out_xy,
-                     uint8_t* d_status, float* d_err);
+                     uint8_t* d_status, float* d_err, uint16_t* d_work = nullptr);
+// d_work (optional), per track: LK iterations executed over all levels | (level passes that iterated) << 8 - what the track cost. The
+// roofline's OPS_lk is summed from these on the host (three atomics per track on shared counters cost the batched launch 14 % of the
+// whole run's throughput: every wavefront of the chip ended on the same three L2 lines).
 
 // Detector cells on the device: CELL_STRIDE ints per cell = (x0, y0, w, h, frame slot index, 0, 0, 0) — the slot index lets one
 // launch serve cells of different frames (several sequences in one batch); `slots` is the base of the frame-slot array.
