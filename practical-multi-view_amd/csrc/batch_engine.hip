@@ -89,7 +89,8 @@ constexpr int MAX_LANES = 4;
 // one waits for its launch, the next takes the requests that have arrived meanwhile instead of letting them sit for a whole round.
 struct Combiner {
     std::thread th;
-    hipStream_t s = nullptr;           // this combiner's own stream
+    hipStream_t s = nullptr;           // this combiner's stream (lanes of a class may share one: BatchEngine::streams)
+    bool owns_stream = true;
     hipEvent_t ev = nullptr;           // blocking-sync event for the interrupt-driven wait
     Growable h_desc{nullptr, 0, true}, d_desc;   // per-batch descriptors (+ stage-in jobs), pinned mirror and device copy
     long batches = 0, requests = 0;
@@ -137,6 +138,10 @@ struct BatchEngine {
     // that is busy all the time - a launch ends with its slowest track, so a single LK stream idles most SIMDs during every tail: PMV_BATCH_LANES
     // sets all classes, PMV_BATCH_LANES_LK / _PNP / _BA one class.
     int lanes[R_COUNT] = {1, 1, 1, 1, 1, 1};
+    // HIP streams per class (<= lanes): lane l launches on stream l % streams. Lanes that share a stream overlap their HOST halves (forming a
+    // round, scattering its results, waking the owners) with each other's kernels while the kernels themselves run one after the other
+    // with every wave slot of the class to themselves; lanes on different streams also overlap their kernels.
+    int streams[R_COUNT] = {0, 0, 0, 0, 0, 0};   // 0 = one per lane
     Queue queue[R_COUNT];
     Combiner comb[R_COUNT][MAX_LANES];
     size_t cap_tracks = 0;
@@ -207,6 +212,10 @@ hipError_t wait_stream(BatchEngine* E, Combiner& C) {
     }
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     C.ema_wait_us = C.ema_wait_us == 0 ? us : 0.8 * C.ema_wait_us + 0.2 * us;
+    // The completion word tells US that the round is over; the runtime has not been asked anything about this stream since the launches.
+    // One query per round lets it retire the round's commands now instead of finding them all still on its books at some later launch.
+    static const bool query_each_round = !(getenv("PMV_BATCH_QUERY") && atoi(getenv("PMV_BATCH_QUERY")) == 0);
+    if (query_each_round) { e = hipStreamQuery(C.s); if (e != hipSuccess && e != hipErrorNotReady) return e; }
     return hipSuccess;
 }
 
@@ -588,13 +597,15 @@ void batch_engine_destroy(pmv_ctx* ctx) {
         Q.cv_new.notify_all();
     }
     for (auto& role : E->comb)
+        for (Combiner& C : role)
+            if (C.th.joinable()) C.th.join();   // all of them first: lanes of a class may share a stream
+    for (auto& role : E->comb)
         for (Combiner& C : role) {
-            if (C.th.joinable()) C.th.join();
             if (getenv("PMV_BATCH_TIMING") && C.batches)
                 fprintf(stderr, "[batch-timing] class %d lane %d: %ld rounds, %.1f req/round, per round: work %.0f us, sync %.0f us (first sleep %.0f us, then %.1f polls), cpu %.0f us, ema %.0f us\n",
                         (int)(&role - &E->comb[0]), (int)(&C - &role[0]), C.batches, (double)C.requests / C.batches, C.t_work / C.batches * 1e6, C.t_sync / C.batches * 1e6,
                         C.t_first_sleep / C.batches * 1e6, (double)C.n_polls / C.batches, C.t_cpu / C.batches * 1e6, C.ema_wait_us);
-            if (C.s) { (void)hipStreamSynchronize(C.s); (void)hipStreamDestroy(C.s); }
+            if (C.s && C.owns_stream) { (void)hipStreamSynchronize(C.s); (void)hipStreamDestroy(C.s); }
             if (C.ev) (void)hipEventDestroy(C.ev);
             if (C.h_done) (void)hipHostFree(C.h_done);
             for (Growable* g : {&C.h_desc, &C.d_desc, &C.h_front, &C.d_front, &C.h_cells, &C.d_cells, &C.d_eig, &C.d_cellmax, &C.d_spill, &C.d_det_xy, &C.d_det_score, &C.d_det_count, &C.h_det}) g->release();
@@ -640,6 +651,9 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
     if (const char* e = getenv("PMV_BATCH_LANES_LK")) E->lanes[R_LK] = std::max(1, std::min(MAX_LANES, atoi(e)));
     if (const char* e = getenv("PMV_BATCH_LANES_PNP")) E->lanes[R_PNP] = std::max(1, std::min(MAX_LANES, atoi(e)));
     if (const char* e = getenv("PMV_BATCH_LANES_BA")) E->lanes[R_BA] = std::max(1, std::min(MAX_LANES, atoi(e)));
+    if (const char* e = getenv("PMV_BATCH_STREAMS_LK")) E->streams[R_LK] = atoi(e);
+    if (const char* e = getenv("PMV_BATCH_STREAMS_BA")) E->streams[R_BA] = atoi(e);
+    if (const char* e = getenv("PMV_BATCH_STREAMS_PNP")) E->streams[R_PNP] = atoi(e);
     if (const char* e = getenv("PMV_BATCH_WAIT")) E->wait_mode = !strcmp(e, "spin") ? 0 : !strcmp(e, "yield") ? 1 : !strcmp(e, "block") ? 2 : 3;
     for (int r = 0; r < R_COUNT; r++)
         for (int l = 0; l < E->lanes[r]; l++) {
@@ -652,7 +666,9 @@ int batch_engine_get(pmv_ctx* ctx, int B, BatchEngine** out) {
             const int prio = !use_prio ? prio_lo : (r == R_BA || r == R_PNP || r == R_DLT) ? prio_hi : prio_lo;
             // (measured and dropped: confining the back-end classes to 64 / 96 CUs with hipExtStreamCreateWithCUMask: 25.4 k -> 16.2 k / 21.3 k
             // frames/s at B = 64 - the PnP hypotheses need the whole chip; equal priorities: no difference either)
-            CKC(hipStreamCreateWithPriority(&C.s, hipStreamNonBlocking, prio));
+            const int n_streams = E->streams[r] > 0 ? std::min(E->streams[r], E->lanes[r]) : E->lanes[r];
+            if (l < n_streams) CKC(hipStreamCreateWithPriority(&C.s, hipStreamNonBlocking, prio));
+            else { C.s = E->comb[r][l % n_streams].s; C.owns_stream = false; }
             CKC(hipEventCreateWithFlags(&C.ev, hipEventBlockingSync | hipEventDisableTiming));
             CKC(hipHostMalloc(&C.h_done, 64, hipHostMallocMapped | hipHostMallocCoherent));
             *C.h_done = 0;
