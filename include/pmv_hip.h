@@ -206,7 +206,8 @@ int pmv_record_get(pmv_ctx* ctx, int i, void* out, long long capacity);
 int pmv_prof_enable(pmv_ctx* ctx, int on);  /* on != 0: reset counters and start recording; 0: stop */
 int pmv_prof_select(pmv_ctx* ctx, unsigned mask); /* after pmv_prof_enable(1): record only classes whose bit (= id) is set */
 int pmv_prof_kernel_count(void);
-/* k_lk work counters since context creation / last reset: out3 = {LK iterations, (track, level) passes, tracks} */
+/* k_lk / k_lk_batch work since context creation / last reset: out3 = {LK iterations, (track, level) passes, tracks}; summed on the
+ * host from a 16-bit word per track that the kernels write next to their results (no device-side atomics) */
 int pmv_lk_counters(pmv_ctx* ctx, unsigned long long* out3, int reset);
 const char* pmv_prof_kernel_name(int id);
 int pmv_prof_read(pmv_ctx* ctx, int id, int* launches, double* total_ms, double* max_ms);

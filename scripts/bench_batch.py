@@ -13,11 +13,19 @@ cfg = dict(w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157)
 n = int(os.environ.get("FRAMES", "1101"))
 Bs = [int(x) for x in sys.argv[1:]] or [8, 16, 32]
 frames, gt = pmv.synth_sequence(1007, 0, n, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16)
+DISTINCT = int(os.environ.get("DISTINCT", "1"))   # >1: bench.py's layout - 4 seeds x start offsets 0/40/80/120, cycled over the slots
+distinct = [(frames, gt)]
+if DISTINCT > 1:
+    OFF, distinct = 40, []
+    for k in range((DISTINCT + 3) // 4):
+        f_, g_ = pmv.synth_sequence(1007 + 64 + k, 0, n + 3 * OFF, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=16)
+        distinct += [(f_[OFF * d: OFF * d + n], g_[OFF * d: OFF * d + n]) for d in range(4)]
+    distinct = distinct[:DISTINCT]
 K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
 Bmax = max(Bs)
 ctx = pmv.Context(cfg["w"], cfg["h"], n_slots=Bmax * n, max_tracks=1024, max_ba_cams=8, max_ba_points=2048, max_ba_obs=16384)
 for b in range(Bmax):
-    ctx.frames_stage(b * n, frames)
+    ctx.frames_stage(b * n, distinct[b % len(distinct)][0])
 if os.environ.get("BA_MODE"):
     ctx.set_ba_mode(int(os.environ["BA_MODE"]))   # 1: one workgroup per solve, one launch per batched BA round
 ref = None
@@ -26,7 +34,7 @@ DEVFP = int(os.environ.get("DEVFP", "0"))
 BA_IT = int(os.environ.get("BA_ITERS", "5"))   # diagnostic: how sensitive is the throughput to the length of the BA launch chain
 print("wait mode", os.environ.get("PMV_BATCH_WAIT", "flag"), "threaded", THREADED, flush=True)
 for B in Bs:
-    seqs = [(b * n, n, gt) for b in range(B)]
+    seqs = [(b * n, n, distinct[b % len(distinct)][1]) for b in range(B)]
     r = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K, want_features=False, defer_free=True, threaded=THREADED, device_fivepoint=DEVFP, ba_iterations=BA_IT)   # warm-up
     ctx.sync()
     s0 = ctx.batch_stats()
@@ -40,7 +48,7 @@ for B in Bs:
     fr = sum(n - int(x.stats["init_offset"]) for x in r2)
     if ref is None:
         ref = r2[0].poses
-    same = all(np.array_equal(x.poses, ref) for x in r2)
+    same = all(np.array_equal(x.poses, r2[i % len(distinct)].poses) for i, x in enumerate(r2))   # (every copy of a distinct sequence gives the same poses)
     print(f"B={B:3d}: {fr / dt:9.1f} frames/s  ({dt:.3f} s)  identical={same}  process CPU {cpu:.2f} s = {cpu / fr * 1e6:.0f} us per frame, {cpu / dt:.1f} cores busy", flush=True)
     keys = [k for k in ("t_lk", "t_detect", "t_pnp", "t_tri", "t_ba", "t_tri_essential", "t_tri_pose", "tri_hypotheses", "tri_ahead") if k in r2[0].stats]
     print("        per frame (wall of the calling threads, us):", {k: round(sum(float(x.stats[k]) for x in r2) / fr * (1.0 if k.startswith("tri_") else 1e6), 2) for k in keys}, flush=True)

@@ -4,11 +4,11 @@ import csv, collections, sys
 d, out = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
 for r in csv.DictReader(open(f"{d}/p_counter_collection.csv")):
-    k = r["Kernel_Name"].split("(")[0].replace("pmv::", "")
+    k = r["Kernel_Name"].split("(")[0].replace("pmv::", "").replace("void ", "").split("<")[0]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
 dur = collections.defaultdict(float); n2 = collections.Counter()
 for r in csv.DictReader(open(f"{d}/p_kernel_trace.csv")):
-    k = r["Kernel_Name"].split("(")[0].replace("pmv::", "")
+    k = r["Kernel_Name"].split("(")[0].replace("pmv::", "").replace("void ", "").split("<")[0]
     dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; n2[k] += 1
 with open(out, "w") as f:
     for k in sorted(acc, key=lambda k: -dur[k]):

@@ -15,7 +15,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("pmv::", "")
+        k = r["Kernel_Name"].split("(")[0].replace("pmv::", "").replace("void ", "").split("<")[0]
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
     return acc

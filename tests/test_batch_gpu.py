@@ -37,16 +37,21 @@ def test_batch_of_different_sequences_equals_single_runs(pmv, gpu_ctx_factory):
     K = np.array([cfg["fx"], 0, cfg["cx"], 0, cfg["fy"], cfg["cy"], 0, 0, 1.0])
     ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=sum(lengths), max_tracks=4096)
     seqs, data = _stage(pmv, ctx, cfg, lengths, seeds)
+    ctx.lk_counters(reset=True)
     got = ctx.pipeline_run_batch(seqs, cfg["w"], cfg["h"], K)
+    lk_work_batch = ctx.lk_counters()
     st = ctx.batch_stats()
     print("combiner statistics:", st)
     for role in ("lk", "pnp", "ba"):
         assert st[role]["requests"] > st[role]["launches"] > 0, f"{role}: nothing was merged into a shared launch"
     single = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=max(lengths), max_tracks=4096)
+    single.lk_counters(reset=True)
     for b, (frames, gt) in enumerate(data):
         single.frames_stage(0, frames)
         ref = single.pipeline_run(lengths[b], cfg["w"], cfg["h"], K, gt, threaded=1)
         _assert_same(got[b], ref, f"sequence {b}")
+    # the measured LK work (iterations, level passes, tracks: the roofline's OPS_lk) of the batched launches = that of the single runs
+    assert lk_work_batch == single.lk_counters() and lk_work_batch[2] > 0
     _assert_same(got[0], got[5], "same input in two batch slots")
     # a second batch on the same engine, in another order and with a different batch size
     again = ctx.pipeline_run_batch([seqs[3], seqs[1], seqs[4]], cfg["w"], cfg["h"], K)

@@ -339,3 +339,22 @@ def test_fast_extractor_matches_oracle(pmv, orc, gpu_ctx_factory):
                     assert np.array_equal(gxy, rxy) and np.array_equal(grs, rrs), (t, nonmax, mx, c)
         assert sum(len(xy) for xy, _ in ctx.detect_fast(0, whole, 1000)) > 100
     assert all(len(xy) == 0 for xy, _ in ctx.detect_fast(0, cells, 0))
+
+
+def test_lk_work_counters_are_summed_from_the_per_track_words(pmv, gpu_ctx_factory):
+    """pmv_lk_counters: iterations / level passes / tracks of the launches since the last reset (bench.py's OPS_lk). The kernels write one 16-bit
+    word per track next to the results and the host sums them (three atomics per track on shared counters cost the batched leg 14 %)."""
+    cfg = dict(w=320, h=240, fx=300.0, fy=300.0, cx=160.0, cy=120.0)
+    frames, _ = pmv.synth_sequence(5, 0, 3, cfg["w"], cfg["h"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], nthreads=4)
+    ctx = gpu_ctx_factory(cfg["w"], cfg["h"], n_slots=3)
+    ctx.frames_stage(0, frames); ctx.frames_build(0, 3)
+    pts = np.concatenate([c for c in ctx.detect_gftt(0, pmv.grid_cells(cfg["w"], cfg["h"]), 20) if len(c)]).astype(np.float32)
+    assert len(pts) > 20
+    ctx.lk_counters(reset=True)
+    ctx.lk_track(0, 1, pts)
+    it1, lv1, n1 = ctx.lk_counters()
+    assert n1 == len(pts) and 0 < lv1 <= 5 * len(pts) and lv1 <= it1 <= 30 * lv1
+    ctx.lk_track(1, 2, pts[:10])
+    it2, lv2, n2 = ctx.lk_counters(reset=True)
+    assert n2 == len(pts) + 10 and it2 > it1 and lv2 > lv1
+    assert tuple(ctx.lk_counters()) == (0, 0, 0)
