@@ -11,6 +11,7 @@
 #include "vo_pipeline.h"
 #include "vo_math.h"
 #include <cfloat>
+#include <emmintrin.h>
 #include <thread>
 
 #include <chrono>
@@ -65,46 +66,69 @@ inline void mac21(P3& r, const P2& a, const P1& b, double s = 1.0) {   // r += s
         for (int j = 0; j < 4; j++) r.c[T.t21[i][j]] += s * (a.c[i] * b.c[j]);
 }
 
-// cv::solvePoly (Durand–Kerner), coeffs ascending, degree n; returns roots (re, im)
-void solve_poly(const double* coeffs_in, int n0, std::vector<std::pair<double, double>>& roots_out) {
-    struct Cx { double re, im; };
-    auto mul = [](Cx a, Cx b) { return Cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; };
-    auto div = [](Cx a, Cx b) { const double t = 1. / (b.re * b.re + b.im * b.im); return Cx{(a.re * b.re + a.im * b.im) * t, (-a.re * b.im + a.im * b.re) * t}; };
+// cv::solvePoly (Durand–Kerner), coeffs ascending, degree n0 <= 10; returns the number of roots, written as (re, im) pairs.
+// The arithmetic is the scalar formulation's, operation for operation (products, sums and their order, one IEEE division per root), so
+// the roots have the same bits; what changed is how it is issued: a complex number is one 128-bit register (two multiplies, one sign
+// flip and one add per complex product instead of four multiplies and two adds), nothing is allocated, and the square root of the
+// convergence test is taken once per sweep (sqrt is monotonic: max over roots of sqrt(x) = sqrt(max x)). This solver is 72 % of the
+// five-point kernel, which is 58 % of the host CPU time of a batched run on distinct sequences.
+namespace {
+typedef __m128d cx;   // (re, im)
+inline cx cx_mul(cx a, cx b) {   // (a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re)
+    const cx x = _mm_mul_pd(_mm_unpacklo_pd(a, a), b);                          // (a.re*b.re, a.re*b.im)
+    const cx y = _mm_mul_pd(_mm_unpackhi_pd(a, a), _mm_shuffle_pd(b, b, 1));    // (a.im*b.im, a.im*b.re)
+    return _mm_add_pd(x, _mm_xor_pd(y, _mm_set_pd(0.0, -0.0)));                 // x0 + (-y0) = x0 - y0 exactly; x1 + y1
+}
+inline double lo(cx a) { return _mm_cvtsd_f64(a); }
+inline double hi(cx a) { return _mm_cvtsd_f64(_mm_unpackhi_pd(a, a)); }
+}  // namespace
+int solve_poly(const double* coeffs_in, int n0, double* roots_out /* 2 * n0 */) {
     int n = n0;
-    std::vector<Cx> coeffs(n0 + 1), roots(n0 + 1);
-    for (int i = 0; i <= n0; i++) coeffs[i] = Cx{coeffs_in[i], 0};
-    for (; n > 1; n--) if (std::abs(coeffs[n].re) + std::abs(coeffs[n].im) > DBL_EPSILON) break;
-    Cx p{1, 0}, r{1, 1};
-    for (int i = 0; i < n; i++) { roots[i] = p; p = mul(p, r); }
+    for (; n > 1; n--) if (std::abs(coeffs_in[n]) + std::abs(0.0) > DBL_EPSILON) break;
+    cx roots[12];
+    cx p = _mm_set_pd(0, 1);
+    const cx r = _mm_set_pd(1, 1);
+    for (int i = 0; i < n; i++) { roots[i] = p; p = cx_mul(p, r); }
+    const cx cn = _mm_set_pd(0, coeffs_in[n]);
     const int maxIters = 300;
+    // (measured and dropped: all Horner values of a sweep up front, four roots per AVX2 instruction - they depend only on where the roots
+    // stood at the sweep's start. Fewer instructions, but out of the shadow of the denominator chains: 11.5 vs 10.9 us per sample on an idle
+    // core, no difference in a loaded batched run, profiles/r03_batch_exp_an.log)
     for (int iter = 0; iter < maxIters; iter++) {
-        double maxDiff = 0;
+        double maxDiff2 = 0;
         for (int i = 0; i < n; i++) {
             p = roots[i];
-            Cx num = coeffs[n], denom = coeffs[n];
+            cx num = cn, denom = cn;
             for (int j = 0; j < n; j++) {
-                num = mul(num, p);
-                num.re += coeffs[n - j - 1].re; num.im += coeffs[n - j - 1].im;
+                num = _mm_add_pd(cx_mul(num, p), _mm_set_pd(0.0, coeffs_in[n - j - 1]));   // (re + c, im + 0.0)
                 if (j != i) {
-                    const Cx d{p.re - roots[j].re, p.im - roots[j].im};
-                    if (d.re != 0 || d.im != 0) denom = mul(denom, d);
+                    const cx d = _mm_sub_pd(p, roots[j]);
+                    if (_mm_movemask_pd(_mm_cmpneq_pd(d, _mm_setzero_pd()))) denom = cx_mul(denom, d);
                 }
             }
-            num = div(num, denom);
-            roots[i] = Cx{p.re - num.re, p.im - num.im};
-            maxDiff = std::max(maxDiff, std::sqrt(num.re * num.re + num.im * num.im));
+            // num / denom: t = 1 / (b.re^2 + b.im^2); ((a.re*b.re + a.im*b.im) * t, (-a.re*b.im + a.im*b.re) * t)
+            const cx bb = _mm_mul_pd(denom, denom);
+            const double t = 1. / (lo(bb) + hi(bb));
+            const cx ab = _mm_mul_pd(num, denom);                              // (a.re*b.re, a.im*b.im)
+            const cx c = _mm_mul_pd(num, _mm_shuffle_pd(denom, denom, 1));     // (a.re*b.im, a.im*b.re)
+            const cx q = _mm_mul_pd(_mm_set_pd(-lo(c) + hi(c), lo(ab) + hi(ab)), _mm_set1_pd(t));
+            roots[i] = _mm_sub_pd(p, q);
+            const cx qq = _mm_mul_pd(q, q);
+            maxDiff2 = std::max(maxDiff2, lo(qq) + hi(qq));
         }
         // cv::solvePoly stops only at maxDiff <= 0 (or after 300 sweeps); the iteration has converged to working precision
         // long before (FIXED CHOICE: stop once no root moved by more than 1e-14 of its magnitude)
+        const double maxDiff = std::sqrt(maxDiff2);
         double scale = 0;
-        for (int i = 0; i < n; i++) scale = std::max(scale, std::fabs(roots[i].re) + std::fabs(roots[i].im));
+        for (int i = 0; i < n; i++) scale = std::max(scale, std::fabs(lo(roots[i])) + std::fabs(hi(roots[i])));
         if (maxDiff <= 1e-14 * (scale > 1.0 ? scale : 1.0)) break;
     }
-    roots_out.clear();
     for (int i = 0; i < n; i++) {
-        if (std::fabs(roots[i].im) < 1e-100) roots[i].im = 0;
-        roots_out.push_back({roots[i].re, roots[i].im});
+        double im = hi(roots[i]);
+        if (std::fabs(im) < 1e-100) im = 0;
+        roots_out[2 * i] = lo(roots[i]); roots_out[2 * i + 1] = im;
     }
+    return n;
 }
 
 // EMEstimatorCallback::runKernel: five normalised correspondences -> up to 10 essential matrices (row-major 3x3 each)
@@ -220,12 +244,12 @@ int five_point_kernel(const double* q1, const double* q2, double* E_out) {
         for (int i = 0; i <= d0; i++) for (int j = 0; j <= d1; j++) t01[i + j] += p0[i] * p1[j];
         for (int i = 0; i <= d0 + d1; i++) for (int j = 0; j <= d2; j++) c[i + j] += pm[3] * t01[i] * p2[j];
     }
-    std::vector<std::pair<double, double>> roots;
-    solve_poly(c, 10, roots);
+    double roots[20];
+    const int n_roots = solve_poly(c, 10, roots);
     int count = 0;
-    for (auto& rt : roots) {
-        if (std::fabs(rt.second) > 1e-10) continue;
-        const double z1 = rt.first, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+    for (int ri = 0; ri < n_roots; ri++) {
+        if (std::fabs(roots[2 * ri + 1]) > 1e-10) continue;
+        const double z1 = roots[2 * ri], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[9];
         for (int j = 0; j < 3; j++) {
             const double* br = b + j * 13;

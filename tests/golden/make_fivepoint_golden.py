@@ -1,0 +1,50 @@
+"""Golden vectors of the five-point kernel (vo::five_point_essentials), produced by the SCALAR formulation of its polynomial solver as it
+stood in commit 84b92ad (before the 128-bit complex arithmetic of round 3): 96 five-point samples (general motion, forward motion, a
+no-motion and a repeated-correspondence case) -> number of models and the 3x3 essential matrices, bit for bit.
+usage (from the repository root, needs git and g++): python tests/golden/make_fivepoint_golden.py"""
+import os, struct, subprocess, tempfile
+from math import cos, sin
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+DUMP = r'''
+#include <cstdio>
+#include <vector>
+namespace vo { int five_point_essentials(const double* q1, const double* q2, double* E_out); }
+int main(int argc, char** argv) {
+    FILE* f = fopen(argv[1], "rb"); int n = 0; if (fread(&n, 4, 1, f) != 1) return 1;
+    std::vector<double> q(20 * (size_t)n); if (fread(q.data(), 8, q.size(), f) != q.size()) return 1; fclose(f);
+    FILE* o = fopen(argv[2], "wb");
+    for (int s = 0; s < n; s++) { double E[90] = {0}; int nm = vo::five_point_essentials(&q[20 * s], &q[20 * s + 10], E); fwrite(&nm, 4, 1, o); fwrite(E, 8, 90, o); }
+    fclose(o);
+}
+'''
+rng = np.random.default_rng(20261005)
+n = 96
+q = np.zeros((n, 20))
+for s in range(n):
+    X, Y, Z = rng.uniform(-10, 10, 5), rng.uniform(-3, 3, 5), rng.uniform(4, 30, 5)
+    t = rng.uniform(-0.2, 0.2, 3) + np.array([0, 0, -0.8]) if s % 3 else rng.uniform(-1, 1, 3)
+    a = rng.uniform(-0.05, 0.05, 3)
+    Rx = np.array([[1, 0, 0], [0, cos(a[0]), -sin(a[0])], [0, sin(a[0]), cos(a[0])]])
+    Ry = np.array([[cos(a[1]), 0, sin(a[1])], [0, 1, 0], [-sin(a[1]), 0, cos(a[1])]])
+    Rz = np.array([[cos(a[2]), -sin(a[2]), 0], [sin(a[2]), cos(a[2]), 0], [0, 0, 1]])
+    P = np.stack([X, Y, Z]); P2 = (Rz @ Ry @ Rx) @ P + t[:, None]
+    q1 = np.stack([P[0] / P[2], P[1] / P[2]], 1) + rng.normal(0, 1e-4, (5, 2))
+    q2 = np.stack([P2[0] / P2[2], P2[1] / P2[2]], 1) + rng.normal(0, 1e-4, (5, 2))
+    if s == 7: q2 = q1.copy()                       # no motion
+    if s == 11: q1[4] = q1[3]; q2[4] = q2[3]        # a repeated correspondence
+    q[s, :10] = q1.ravel(); q[s, 10:] = q2.ravel()
+with tempfile.TemporaryDirectory() as d:
+    open(f"{d}/old_fp.cpp", "w").write(subprocess.run(["git", "-C", ROOT, "show", "84b92ad:practical-multi-view_amd/host/vo_fivepoint.cpp"], check=True, capture_output=True, text=True).stdout)
+    open(f"{d}/dump.cpp", "w").write(DUMP)
+    host = f"{ROOT}/practical-multi-view_amd/host"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-I", host, "-I", f"{ROOT}/include", f"{d}/dump.cpp", f"{d}/old_fp.cpp", f"{host}/vo_pipeline.cpp", "-o", f"{d}/dump"], check=True)
+    open(f"{d}/in.bin", "wb").write(struct.pack("i", n) + q.tobytes())
+    subprocess.run([f"{d}/dump", f"{d}/in.bin", f"{d}/out.bin"], check=True)
+    raw = open(f"{d}/out.bin", "rb").read()
+rec = 4 + 90 * 8
+nm = np.array([struct.unpack_from("i", raw, i * rec)[0] for i in range(n)], np.int32)
+E = np.stack([np.frombuffer(raw, np.float64, 90, i * rec + 4) for i in range(n)])
+out = os.path.join(ROOT, "tests", "golden", "fivepoint_kernel_scalar.npz")
+np.savez_compressed(out, q=q, n_models=nm, E=E)
+print("models per sample:", nm.tolist(), "->", out, os.path.getsize(out), "bytes")

@@ -5,6 +5,7 @@ source (OdometryPipeline.cpp:171-208, OpenCVFivePointTri.cpp:24-27) and an indep
 RANSACPointSetRegistrator::getSubset / RANSACUpdateNumIters (SURVEY.md A.3, A.4). No GPU needed."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -277,3 +278,17 @@ def test_motion_heuristics_accept_reject_and_fallback(orc):
                                             _p(np.eye(3).reshape(9).copy(), _f64p), _p(np.array([0.0, 0.0, -0.8]), _f64p), _p(Ra, _f64p), _p(ta, _f64p),
                                             _p(Rr, _f64p), _p(tr, _f64p))
     assert fb == 0 and ta.tolist() == [0.0, 0.0, -0.8] and tr.tolist() == [0.0, 0.0, -0.8] and np.array_equal(Ra.reshape(3, 3), np.eye(3))
+
+
+def test_five_point_kernel_equals_the_scalar_formulation_bit_for_bit(orc):
+    """The polynomial solver of the five-point kernel runs on 128-bit complex arithmetic since round 3 (two multiplies, a sign flip and an
+    add per complex product). tests/golden/fivepoint_kernel_scalar.npz holds what the scalar formulation of commit 84b92ad returned for 96
+    samples (make_fivepoint_golden.py): same number of models, same bits."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fivepoint_kernel_scalar.npz"))
+    q, want_n, want_E = g["q"], g["n_models"], g["E"]
+    assert len(q) == 96 and want_n.min() == 0 and want_n.max() >= 6
+    for s in range(len(q)):
+        Es = np.zeros(90)
+        n = orc.lib.orc_host_five_point(_p(np.ascontiguousarray(q[s, :10]), _f64p), _p(np.ascontiguousarray(q[s, 10:]), _f64p), _p(Es, _f64p))
+        assert n == want_n[s], f"sample {s}: {n} models instead of {want_n[s]}"
+        assert np.array_equal(Es[: 9 * n].view(np.uint64), want_E[s, : 9 * n].view(np.uint64)), f"sample {s}: essential matrices differ in their bits"
