@@ -965,6 +965,9 @@ __global__ __launch_bounds__(256) void k_gftt_cand(const uint8_t* __restrict__ s
 // a round is a serial chain (arg-max -> accept -> kill) and costs ~2.9 k cycles whatever the operand width (64-bit keys: 3.4 k) - a lone or
 // nearly lone wavefront issues one DEPENDENT instruction every 10-30 cycles, so the chain's instruction count is what matters; ONE wavefront
 // per cell (no exchange, no barrier, 12 slots per lane) takes 9.6 k cycles per round: the slots' instructions do not overlap, they queue.
+// SORTING the records once (bitonic network over the LDS list, 55 stages for 1024 records) and letting one wavefront walk the sorted list 64
+// records at a time (accept in list order unless an accepted corner is closer than minDistance: OpenCV's loop verbatim, bit-exact in every
+// test) took 84 us per launch instead of 60: a stage with its barrier costs ~1 us, not the 200 cycles of its instruction count.
 constexpr int GP_T = 256, GP_SLOTS = 16, GP_REG = GP_T * GP_SLOTS, GP_MAXOUT = 4096;   // GP_MAXOUT = MAX_PER_CELL of pmv_ctx.h
 __global__ __launch_bounds__(GP_T) void k_gftt_pick(const int* __restrict__ cells, float* __restrict__ cand_val, unsigned* __restrict__ cand_idx,
                                                     const unsigned* __restrict__ cellinfo, int max_corners, double quality, double min_dist,
