@@ -180,3 +180,16 @@ def test_initialise_quirks_q5_q6(pmv, twin):
         assert_same(t2, o2)
         v2 = run_twin(twin, fr, K2, g, variant=64, **kw2)
         print(f"seed {seed}: init_offset with score term {t2.counters['init_offset']}, without {v2.counters['init_offset']}")
+
+
+def test_retired_frames_export_what_live_frames_would(pmv, twin):
+    """The shared orchestration retires frames that left the bundle window (their tables are recycled, exports come from a compact copy).
+    Without bundle adjustment (bundle_size 0) the window is the shortest there is - every frame but the last few is retired during the run -
+    and the exports still equal the twin's, which keeps every frame in the reference's own containers; both schedules."""
+    frames, K, gt, kw, _ = small_case(pmv)
+    kw = dict(kw, bundle_size=0)
+    t = run_twin(twin, frames, K, gt, **kw)
+    for threaded in (0, 1):
+        o = ob.run_pipeline(frames, K, gt, threaded=threaded, n_threads=2, **kw)
+        assert_same(t, o)
+    assert len(t.features) == len(frames) - t.counters["init_offset"] if "init_offset" in t.counters else True
