@@ -72,6 +72,8 @@ __device__ inline int fp_solve_poly(const double* coeffs_in, int n0, double* rre
         const double tre = pre * 1.0 - pim * 1.0, tim = pre * 1.0 + pim * 1.0;   // p = p * (1 + i)
         pre = tre; pim = tim;
     }
+    double best_diff = DBL_MAX;
+    int since_best = 0;
     #pragma unroll 1
     for (int iter = 0; iter < 300; iter++) {
         double maxDiff = 0;
@@ -101,7 +103,10 @@ __device__ inline int fp_solve_poly(const double* coeffs_in, int n0, double* rre
         double scale = 0;
         #pragma unroll 1
         for (int i = 0; i < n; i++) { const double v = fabs(rre[i]) + fabs(rim[i]); scale = v > scale ? v : scale; }
-        if (maxDiff <= 1e-14 * (scale > 1.0 ? scale : 1.0)) break;
+        const double lim = scale > 1.0 ? scale : 1.0;
+        if (maxDiff <= 1e-14 * lim) break;
+        if (maxDiff < 0.5 * best_diff) { best_diff = maxDiff; since_best = 0; }   // (the stall rule of vo_fivepoint.cpp:solve_poly)
+        else if (maxDiff <= 1e-6 * lim && ++since_best >= 10) break;
     }
     #pragma unroll 1
     for (int i = 0; i < n; i++) if (fabs(rim[i]) < 1e-100) rim[i] = 0;

@@ -282,8 +282,8 @@ def test_motion_heuristics_accept_reject_and_fallback(orc):
 
 def test_five_point_kernel_equals_the_scalar_formulation_bit_for_bit(orc):
     """The polynomial solver of the five-point kernel runs on 128-bit complex arithmetic since round 3 (two multiplies, a sign flip and an
-    add per complex product). tests/golden/fivepoint_kernel_scalar.npz holds what the scalar formulation of commit 84b92ad returned for 96
-    samples (make_fivepoint_golden.py): same number of models, same bits."""
+    add per complex product). tests/golden/fivepoint_kernel_scalar.npz holds what the scalar formulation of commit 84b92ad (with the stall
+    rule of the same round patched in) returns for 96 samples (make_fivepoint_golden.py): same number of models, same bits."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fivepoint_kernel_scalar.npz"))
     q, want_n, want_E = g["q"], g["n_models"], g["E"]
     assert len(q) == 96 and want_n.min() == 0 and want_n.max() >= 6
