@@ -7,7 +7,8 @@
 // degree-10 polynomial rooted by the Durand–Kerner iteration of cv::solvePoly, four-fold (R,t) cheirality test with DLT
 // triangulation.  FIXED CHOICES: the 5x9 null space by Gauss–Jordan elimination (any basis of it gives the same E set), other
 // null vectors via cyclic-Jacobi eigenvectors of A^T A; the 10x20 constraint matrix is built by explicit polynomial algebra in
-// Nistér's monomial order instead of OpenCV's generated coefficient table; Durand–Kerner stops at 1e-14 relative movement.
+// Nistér's monomial order instead of OpenCV's generated coefficient table; Durand–Kerner stops at 1e-14 relative movement, or when the
+// movement has stopped shrinking (round-off floor of clustered roots: solve_poly's stall rule).
 #include "vo_pipeline.h"
 #include "vo_math.h"
 #include <cfloat>
